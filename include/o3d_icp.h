@@ -1,0 +1,146 @@
+/*
+ * o3d_icp.h -- C ABI of the MI355X-native ICP registration hot path.
+ *
+ * Drop-in boundary for PolyCam/open3d's legacy registration pipeline.  The
+ * reference has no FFI layer of its own (its boundary is ordinary C++,
+ * SURVEY.md section 8b); each entry point below names the reference function
+ * (file:line under /root/reference/open3d/) whose work it replaces.  The C++
+ * adapter with the reference's own signatures lives in
+ * open3d_amd/cpp/open3d_amd_registration.h; INTEGRATION.md shows the patch a
+ * maintainer of the reference would apply.
+ *
+ * Conventions
+ *  - points / normals: contiguous double[3] per point (std::vector<Eigen::Vector3d>
+ *    storage, geometry/PointCloud.h:330-334); 4x4 matrices: 16 doubles COLUMN-major
+ *    (Eigen::Matrix4d default storage).
+ *  - correspondences: int32 corr[n_src], corr[i] = target index or -1; the
+ *    reference's CorrespondenceSet is the ascending-i list of (i, corr[i]) >= 0
+ *    (pipelines/registration/Registration.cpp:60-68 run serially).
+ *  - every function returns an o3d_status (0 = ok) and never throws; the text for
+ *    the last failure on a context is available from o3d_last_error().
+ *  - `mem` says where the caller's bulk buffers live (host or device).  Scalars and
+ *    4x4 matrices are always host memory.
+ *  - a context owns one GPU, one stream and all scratch buffers; one call in flight
+ *    per context, any number of contexts per process.
+ *  - there is NO CPU fallback: without a usable HIP device every call fails with
+ *    O3D_ERR_HIP.
+ */
+#ifndef O3D_ICP_H_
+#define O3D_ICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define O3D_API __attribute__((visibility("default")))
+#else
+#define O3D_API
+#endif
+
+typedef struct o3d_ctx o3d_ctx;
+
+typedef enum {
+  O3D_OK = 0,
+  O3D_ERR_INVALID_DISTANCE = 1, /* Registration.cpp:134-136 "Invalid max_correspondence_distance." */
+  O3D_ERR_NEED_NORMALS = 2,     /* Registration.cpp:137-144 point-to-plane without target normals */
+  O3D_ERR_VOXEL_SIZE = 3,       /* geometry/PointCloud.cpp:275-277 "voxel_size <= 0." */
+  O3D_ERR_VOXEL_TOO_SMALL = 4,  /* geometry/PointCloud.cpp:281-283 "voxel_size is too small." */
+  O3D_ERR_INVALID_ARG = 5,
+  O3D_ERR_HIP = 6,              /* HIP runtime failure or no device */
+  O3D_ERR_OOM = 7,
+  O3D_ERR_STATE = 8,            /* stepwise API called out of order */
+  O3D_ERR_UNSUPPORTED = 9
+} o3d_status;
+
+typedef enum { O3D_MEM_HOST = 0, O3D_MEM_DEVICE = 1 } o3d_mem;
+
+/* TransformationEstimationType, pipelines/registration/TransformationEstimation.h:45-50 */
+typedef enum { O3D_EST_POINT_TO_POINT = 1, O3D_EST_POINT_TO_PLANE = 2 } o3d_estimation;
+
+/* KDTreeSearchParam::SearchType, geometry/KDTreeSearchParam.h:35-107 */
+typedef enum { O3D_SEARCH_KNN = 0, O3D_SEARCH_RADIUS = 1, O3D_SEARCH_HYBRID = 2 } o3d_search;
+
+/* ---- context -------------------------------------------------------------- */
+O3D_API int o3d_ctx_create(int device_id, o3d_ctx **out_ctx);
+O3D_API void o3d_ctx_destroy(o3d_ctx *ctx);
+/* Launch everything on an existing hipStream_t (e.g. torch's current stream).  NULL = the context's own stream. */
+O3D_API int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream);
+O3D_API const char *o3d_last_error(const o3d_ctx *ctx);
+O3D_API const char *o3d_status_string(int status);
+/* 1 when the library was built for and sees a gfx950 device */
+O3D_API int o3d_device_count(void);
+
+/* ---- whole-call drop-ins ---------------------------------------------------- */
+
+/* RegistrationICP, pipelines/registration/Registration.cpp:129-168 (driver), with
+ * GetRegistrationResultAndCorrespondences :41-91, KDTreeFlann::SearchHybrid
+ * geometry/KDTreeFlann.cpp:132-152, PointCloud::Transform geometry/Geometry3D.cpp:77-89,
+ * TransformationEstimationPointToPoint/PointToPlane::ComputeTransformation
+ * TransformationEstimation.cpp:49-60,74-98 and utility::ComputeJTJandJTr
+ * utility/Eigen.cpp:159-201 fused on the device.
+ * tgt_nrm may be NULL for point-to-point.  out_corr may be NULL. */
+O3D_API int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                         int64_t n_tgt, double max_correspondence_distance, const double init_colmajor[16], int estimation,
+                         int with_scaling, double relative_fitness, double relative_rmse, int max_iteration, int mem,
+                         double out_transformation[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
+                         double *out_inlier_rmse, int *out_iterations);
+
+/* EvaluateRegistration, pipelines/registration/Registration.cpp:118-127 */
+O3D_API int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                              double max_correspondence_distance, const double transformation_colmajor[16], int mem,
+                              int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
+
+/* ---- stepwise, device-resident ICP (same loop, caller owns the per-iteration
+ *      exchange; used by the sharded multi-GPU driver and by bench.py) -------- */
+
+/* Builds the target grid (replaces KDTreeFlann::SetGeometry, geometry/KDTreeFlann.cpp:58-73,154-167),
+ * uploads/permutes the source shard and stores init and the criteria (Registration.cpp:146-152).
+ * n_src_global: number of source points over ALL shards (fitness denominator, Registration.cpp:87); pass
+ * n_src when not sharded. */
+O3D_API int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                  int64_t n_tgt, double max_correspondence_distance, const double init_colmajor[16], int estimation,
+                  int with_scaling, double relative_fitness, double relative_rmse, int max_iteration, int mem,
+                  int64_t n_src_global);
+/* Enqueue one fused pass: apply the pending update to the source shard (Registration.cpp:159), find
+ * correspondences (:161) and reduce this shard's JTJ/JTr (or Umeyama) sums for the next estimate (:157).
+ * The 32 fp64 partial sums land in the device buffer returned by o3d_icp_local_sums(). */
+O3D_API int o3d_icp_pass(o3d_ctx *ctx);
+O3D_API double *o3d_icp_local_sums(o3d_ctx *ctx); /* device pointer, 32 doubles */
+/* Enqueue the estimate: sums `n_ranks` x 32 doubles (device pointer, rank-major, added in rank order so every
+ * rank gets bit-identical results), then fitness/rmse (Registration.cpp:82-89), the convergence test
+ * (:162-165), the 6x6 LDLT solve or Umeyama SVD, update composition (:158).  Pass the pointer from
+ * o3d_icp_local_sums() and n_ranks = 1 when not sharded. */
+O3D_API int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
+/* Synchronise and report whether the loop has ended (converged or max_iteration reached). */
+O3D_API int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes);
+/* Synchronise and fetch the RegistrationResult (Registration.h:107-126).  out_corr (n_src entries, `mem` space, may be
+ * NULL) is in the caller's original source order. */
+O3D_API int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_transformation[16], int32_t *out_corr, int64_t *out_n_corr,
+                   double *out_fitness, double *out_inlier_rmse, int *out_iterations);
+/* Per-pass history for parity tests: row p = {fitness, rmse, n_corr, sum_d2, T[16] colmajor, sums[32]} = 52 doubles. */
+#define O3D_LOG_STRIDE 52
+O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows);
+/* Timing breakdown of the last setup (milliseconds, HIP events): [0] grid build, [1] source upload+sort. */
+O3D_API int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]);
+
+/* ---- preprocessing ---------------------------------------------------------- */
+
+/* PointCloud::VoxelDownSample, geometry/PointCloud.cpp:273-306.  nrm / col may be NULL.  Output buffers must hold
+ * n entries (the voxel count M <= n is returned in *out_m).  Output order: ascending voxel index (z, y, x); the
+ * reference's order is unordered_map bucket order (unspecified).  out_voxel_index (3 x int32 per voxel) may be NULL. */
+O3D_API int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n,
+                          double voxel_size, int mem, double *out_xyz, double *out_nrm, double *out_col,
+                          int32_t *out_voxel_index, int64_t *out_m);
+
+/* PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351 with ComputeNormal :215-252 and FastEigen3x3
+ * :130-213 (fast_normal_computation = true, the reference default).  normals is in/out when has_normals != 0. */
+O3D_API int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                         double *normals, int has_normals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3D_ICP_H_ */

@@ -1,0 +1,146 @@
+"""ctypes binding of libo3d_amd.so (the C ABI declared in include/o3d_icp.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is
+missing, or no HIP device is usable, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libo3d_amd.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+EST_POINT_TO_POINT, EST_POINT_TO_PLANE = 1, 2
+SEARCH_KNN, SEARCH_RADIUS, SEARCH_HYBRID = 0, 1, 2
+LOG_STRIDE = 52
+STATUS_OK = 0
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+
+_SIGNATURES = {
+    "o3d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "o3d_ctx_destroy": (None, [C.c_void_p]),
+    "o3d_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "o3d_last_error": (C.c_char_p, [C.c_void_p]),
+    "o3d_status_string": (C.c_char_p, [C.c_int]),
+    "o3d_device_count": (C.c_int, []),
+    "o3d_registration_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                       c_dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, c_dp, C.c_void_p,
+                                       C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int)]),
+    "o3d_evaluate_registration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp,
+                                            C.c_int, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp]),
+    "o3d_icp_setup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, c_dp,
+                                C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64]),
+    "o3d_icp_pass": (C.c_int, [C.c_void_p]),
+    "o3d_icp_local_sums": (C.c_void_p, [C.c_void_p]),
+    "o3d_icp_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "o3d_icp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "o3d_icp_finish": (C.c_int, [C.c_void_p, C.c_int, c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp,
+                                 C.POINTER(C.c_int)]),
+    "o3d_icp_get_log": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.POINTER(C.c_int)]),
+    "o3d_icp_get_setup_ms": (C.c_int, [C.c_void_p, c_dp]),
+    "o3d_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "o3d_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                       C.c_int]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """dlopen libo3d_amd.so.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C open3d_amd/csrc` (or __graft_entry__.build()); "
+                               "open3d_amd has no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class O3DError(RuntimeError):
+    """Mirror of the std::runtime_error thrown by utility::LogError (utility/Console.h:82-87)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def colmajor(T):
+    """4x4 numpy (math layout) -> 16 doubles in Eigen::Matrix4d storage order."""
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("expected a 4x4 matrix")
+    return np.ascontiguousarray(T.T).reshape(16)
+
+
+def from_colmajor(flat):
+    return np.array(flat, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+class Context:
+    """One GPU + one stream + scratch memory (o3d_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        st = self._lib.o3d_ctx_create(int(device), C.byref(h))
+        if st != STATUS_OK:
+            raise O3DError(st, "o3d_ctx_create(%d) failed: %s" % (device, self._lib.o3d_last_error(None).decode()))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.o3d_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st != STATUS_OK:
+            msg = self._lib.o3d_last_error(self._h).decode() or self._lib.o3d_status_string(st).decode()
+            raise O3DError(st, msg)
+
+    def set_stream(self, stream_handle):
+        self.check(self._lib.o3d_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    @property
+    def handle(self):
+        return self._h
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def ptr(a):
+    """Raw address of a numpy array (host) or of anything with data_ptr() (torch device tensor); None -> NULL."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,406 @@
+// C ABI of libo3d_amd.so (declared in include/o3d_icp.h): context management and the host-side driver of the
+// device-resident ICP loop (reference pipelines/registration/Registration.cpp:118-168).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "o3d_internal.h"
+
+int o3d_launch_pass(o3d_ctx *ctx);
+int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
+int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
+int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
+                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
+int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                              double *normals, int has_normals);
+
+static thread_local std::string g_err_noctx;
+
+int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else g_err_noctx = buf;
+  return status;
+}
+
+int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes) {
+  if (bytes <= *cap && *ptr) return O3D_OK;
+  if (*ptr) {
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+  }
+  size_t want = bytes < 256 ? 256 : bytes;
+  O3D_HIP(ctx, hipMalloc(ptr, want));
+  *cap = want;
+  return O3D_OK;
+}
+
+int o3d_scratch(o3d_ctx *ctx, int slot, size_t bytes, void **out) {
+  O3D_TRY(o3d_reserve(ctx, &ctx->scratch[slot], &ctx->scratch_cap[slot], bytes));
+  *out = ctx->scratch[slot];
+  return O3D_OK;
+}
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// Eigen::Matrix4d::isIdentity() with dummy_precision 1e-12 (Registration.cpp:123,150)
+bool is_identity(const double *T) {
+  const double prec = 1e-12;
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      const double v = T[c * 4 + r];
+      if (r == c) {
+        const double m = fabs(v) < 1.0 ? fabs(v) : 1.0;
+        if (!(fabs(v - 1.0) <= prec * m)) return false;
+      } else if (!(fabs(v) <= prec)) {
+        return false;
+      }
+    }
+  return true;
+}
+
+// Bring a caller buffer to the device (no-op for device memory).  slot = scratch slot used for the copy.
+int to_device(o3d_ctx *ctx, const void *p, size_t bytes, int mem, void **slot_ptr, size_t *slot_cap, const void **out) {
+  if (mem == O3D_MEM_DEVICE || p == nullptr || bytes == 0) { *out = p; return O3D_OK; }
+  O3D_TRY(o3d_reserve(ctx, slot_ptr, slot_cap, bytes));
+  O3D_HIP(ctx, hipMemcpyAsync(*slot_ptr, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *out = *slot_ptr;
+  return O3D_OK;
+}
+
+}  // namespace
+
+struct o3d_staging {  // host->device staging of caller buffers (kept on the context, grow-only)
+  void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+};
+static o3d_staging *staging_of(o3d_ctx *ctx);
+
+extern "C" {
+
+int o3d_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *o3d_status_string(int s) {
+  switch (s) {
+    case O3D_OK: return "ok";
+    case O3D_ERR_INVALID_DISTANCE: return "[Open3D ERROR] Invalid max_correspondence_distance.";
+    case O3D_ERR_NEED_NORMALS:
+      return "[Open3D ERROR] TransformationEstimationPointToPlane and TransformationEstimationColoredICP require "
+             "pre-computed normal vectors for target PointCloud.";
+    case O3D_ERR_VOXEL_SIZE: return "[Open3D ERROR] [VoxelDownSample] voxel_size <= 0.";
+    case O3D_ERR_VOXEL_TOO_SMALL: return "[Open3D ERROR] [VoxelDownSample] voxel_size is too small.";
+    case O3D_ERR_INVALID_ARG: return "invalid argument";
+    case O3D_ERR_HIP: return "HIP runtime error";
+    case O3D_ERR_OOM: return "out of device memory";
+    case O3D_ERR_STATE: return "call out of order";
+    case O3D_ERR_UNSUPPORTED: return "unsupported";
+  }
+  return "unknown status";
+}
+
+const char *o3d_last_error(const o3d_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
+
+}  // extern "C"
+
+struct o3d_ctx_full : o3d_ctx {
+  o3d_staging stage;
+};
+static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
+
+extern "C" {
+
+int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
+  if (!out_ctx) return O3D_ERR_INVALID_ARG;
+  *out_ctx = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return o3d_fail(nullptr, O3D_ERR_HIP, "no HIP device available (%s); libo3d_amd has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return o3d_fail(nullptr, O3D_ERR_INVALID_ARG, "device %d out of range [0,%d)", device_id, ndev);
+  o3d_ctx_full *ctx = new (std::nothrow) o3d_ctx_full();
+  if (!ctx) return O3D_ERR_OOM;
+  ctx->device = device_id;
+  DeviceGuard guard(device_id);
+  auto bail = [&](hipError_t err, const char *what) {
+    o3d_fail(nullptr, O3D_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+    o3d_ctx_destroy(ctx);
+    return (int)O3D_ERR_HIP;
+  };
+  if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  ctx->stream = ctx->own_stream;
+  if ((e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+  if ((e = hipMalloc((void **)&ctx->state, sizeof(IcpState))) != hipSuccess) return bail(e, "hipMalloc state");
+  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
+  if ((e = hipMalloc((void **)&ctx->sums, sizeof(double) * O3D_NSUMS)) != hipSuccess) return bail(e, "hipMalloc sums");
+  *out_ctx = ctx;
+  return O3D_OK;
+}
+
+void o3d_ctx_destroy(o3d_ctx *c) {
+  if (!c) return;
+  o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
+  DeviceGuard guard(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void *bufs[] = {ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
+                  ctx->corr_out,   ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  for (int i = 0; i < 8; i++)
+    if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  for (int i = 0; i < 4; i++)
+    if (ctx->stage.p[i]) (void)hipFree(ctx->stage.p[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return O3D_OK;
+}
+
+int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
+                  double max_dist, const double init[16], int estimation, int with_scaling, double rel_fitness, double rel_rmse,
+                  int max_iter, int mem, int64_t n_src_global) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  ctx->icp_ready = 0;
+  if (!(max_dist > 0.0)) return o3d_fail(ctx, O3D_ERR_INVALID_DISTANCE, "%s", o3d_status_string(O3D_ERR_INVALID_DISTANCE));
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path", estimation);
+  if (estimation == O3D_EST_POINT_TO_PLANE && (!tgt_nrm || n_tgt <= 0))
+    return o3d_fail(ctx, O3D_ERR_NEED_NORMALS, "%s", o3d_status_string(O3D_ERR_NEED_NORMALS));
+  if (n_src < 0 || n_tgt < 0 || !init || (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz) || max_iter < 0)
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
+  if (n_src >= ((int64_t)1 << 31) || n_tgt >= ((int64_t)1 << 31))
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "clouds are limited to 2^31-1 points per GPU (the reference indexes with int)");
+  if (n_src_global < n_src) n_src_global = n_src;
+  DeviceGuard guard(ctx->device);
+  o3d_staging *sg = staging_of(ctx);
+
+  hipEvent_t ev[3];
+  for (auto &e : ev) O3D_HIP(ctx, hipEventCreate(&e));
+  O3D_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+
+  const void *d_tgt, *d_nrm, *d_src;
+  O3D_TRY(to_device(ctx, tgt_xyz, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[0], &sg->cap[0], &d_tgt));
+  O3D_TRY(to_device(ctx, estimation == O3D_EST_POINT_TO_PLANE ? tgt_nrm : nullptr, sizeof(double) * 3 * (size_t)n_tgt, mem,
+                    &sg->p[1], &sg->cap[1], &d_nrm));
+  O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist));
+  O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+
+  const int apply_init = is_identity(init) ? 0 : 1;  // Registration.cpp:150-152
+  O3D_TRY(to_device(ctx, src_xyz, sizeof(double) * 3 * (size_t)n_src, mem, &sg->p[2], &sg->cap[2], &d_src));
+  O3D_TRY(o3d_sort_source(ctx, (const double *)d_src, n_src, init, apply_init));
+  O3D_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+
+  // loop state
+  ctx->estimation = estimation;
+  ctx->thr = (double)(float)(max_dist * max_dist);  // geometry/KDTreeFlann.cpp:148
+  ctx->max_iter = max_iter;
+  int64_t g = (n_src + O3D_BLOCK - 1) / O3D_BLOCK;
+  if (g < 1) g = 1;
+  if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  ctx->pass_grid = (int)g;
+  const int rows = max_iter + 1;
+  if (rows > ctx->log_rows || !ctx->log) {
+    if (ctx->log) (void)hipFree(ctx->log);
+    ctx->log = nullptr;
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->log, sizeof(double) * O3D_LOG_STRIDE * (size_t)rows));
+    ctx->log_rows = rows;
+  }
+  IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
+  memset(hs, 0, sizeof(IcpState));
+  for (int i = 0; i < 16; i++) { hs->T[i] = init[i]; hs->update[i] = init[i]; }
+  hs->rel_fitness = rel_fitness;
+  hs->rel_rmse = rel_rmse;
+  hs->n_src_global = (double)n_src_global;
+  hs->max_iter = max_iter;
+  hs->apply_update = apply_init;
+  hs->estimation = estimation;
+  hs->with_scaling = with_scaling;
+  // fixed origin for the Umeyama moments: centre of the target's bounding box (cuts cancellation, any value is valid)
+  for (int d = 0; d < 3; d++) hs->centre[d] = ctx->gp.gmin[d] + 0.5 * ctx->gp.h * (double)(d == 0 ? ctx->gp.nx : (d == 1 ? ctx->gp.ny : ctx->gp.nz));
+  O3D_HIP(ctx, hipMemcpyAsync(ctx->state, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms0 = 0, ms1 = 0;
+  (void)hipEventElapsedTime(&ms0, ev[0], ev[1]);
+  (void)hipEventElapsedTime(&ms1, ev[1], ev[2]);
+  ctx->setup_ms[0] = ms0;
+  ctx->setup_ms[1] = ms1;
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  ctx->enq_passes = 0;
+  ctx->icp_ready = 1;
+  return O3D_OK;
+}
+
+int o3d_icp_pass(o3d_ctx *ctx) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  ctx->enq_passes++;
+  return o3d_launch_pass(ctx);
+}
+
+double *o3d_icp_local_sums(o3d_ctx *ctx) { return ctx ? ctx->sums : nullptr; }
+
+int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks) {
+  if (!ctx || !dev_all_sums || n_ranks < 1) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_solve before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  return o3d_launch_solve(ctx, dev_all_sums, n_ranks);
+}
+
+int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_poll before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
+  O3D_HIP(ctx, hipMemcpyAsync(hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_done) *out_done = hs->done;
+  if (out_passes) *out_passes = hs->passes;
+  return O3D_OK;
+}
+
+int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
+                   double *out_rmse, int *out_iters) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_finish before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  if (out_corr && ctx->n_src > 0) {
+    if (mem == O3D_MEM_DEVICE) {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, out_corr));
+    } else {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, ctx->corr_out));
+      O3D_HIP(ctx, hipMemcpyAsync(out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
+  O3D_HIP(ctx, hipMemcpyAsync(hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out_T) memcpy(out_T, hs->T, sizeof(double) * 16);
+  if (out_n_corr) *out_n_corr = (int64_t)hs->n_corr;
+  if (out_fitness) *out_fitness = hs->fitness;
+  if (out_rmse) *out_rmse = hs->rmse;
+  if (out_iters) *out_iters = hs->iters;
+  return O3D_OK;
+}
+
+int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows) {
+  if (!ctx || !host_log) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_get_log before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  int done = 0, passes = 0;
+  O3D_TRY(o3d_icp_poll(ctx, &done, &passes));
+  int rows = passes < max_rows ? passes : max_rows;
+  if (rows > ctx->log_rows) rows = ctx->log_rows;
+  if (rows > 0) {
+    O3D_HIP(ctx, hipMemcpyAsync(host_log, ctx->log, sizeof(double) * O3D_LOG_STRIDE * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (out_rows) *out_rows = rows;
+  return O3D_OK;
+}
+
+int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
+  if (!ctx || !out_ms) return O3D_ERR_INVALID_ARG;
+  out_ms[0] = ctx->setup_ms[0];
+  out_ms[1] = ctx->setup_ms[1];
+  return O3D_OK;
+}
+
+int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                         int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
+                         double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
+                         int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
+                        rel_rmse, max_iter, mem, n_src));
+  // Registration.cpp:154-166.  The whole loop is enqueued without host round trips; kernels past the break are
+  // no-ops (IcpState::done).  The host looks at the flag every kChunk iterations to stop enqueueing early.
+  const int kChunk = 6;
+  O3D_TRY(o3d_icp_pass(ctx));
+  O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
+  int it = 0;
+  while (it < max_iter) {
+    const int upto = it + kChunk < max_iter ? it + kChunk : max_iter;
+    for (; it < upto; it++) {
+      O3D_TRY(o3d_icp_pass(ctx));
+      O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
+    }
+    if (it < max_iter) {
+      int done = 0;
+      O3D_TRY(o3d_icp_poll(ctx, &done, nullptr));
+      if (done) break;
+    }
+  }
+  return o3d_icp_finish(ctx, mem, out_T, out_corr, out_n_corr, out_fitness, out_rmse, out_iters);
+}
+
+int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                              double max_dist, const double T[16], int mem, int32_t *out_corr, int64_t *out_n_corr,
+                              double *out_fitness, double *out_rmse) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!(max_dist > 0.0)) {  // Registration.cpp:45-47: an empty result, not an error
+    DeviceGuard guard(ctx->device);
+    if (out_corr && n_src > 0) {
+      if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        memset(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src);
+      }
+    }
+    if (out_n_corr) *out_n_corr = 0;
+    if (out_fitness) *out_fitness = 0.0;
+    if (out_rmse) *out_rmse = 0.0;
+    return O3D_OK;
+  }
+  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem, n_src));
+  O3D_TRY(o3d_icp_pass(ctx));
+  O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
+  return o3d_icp_finish(ctx, mem, nullptr, out_corr, out_n_corr, out_fitness, out_rmse, nullptr);
+}
+
+int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel_size,
+                          int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_voxel_index, int64_t *out_m) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  return o3d_voxel_down_sample_impl(ctx, xyz, nrm, col, n, voxel_size, mem, out_xyz, out_nrm, out_col, out_voxel_index, out_m);
+}
+
+int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                         double *normals, int has_normals) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Uniform cell grid over the target cloud: the replacement for KDTreeFlann::SetGeometry
+// (reference geometry/KDTreeFlann.cpp:58-73,154-167) on the ICP path.
+//
+// Layout in HBM
+//   tgt_sorted[n]  : double4 {x, y, z, bits(original index)} ordered by cell key (x fastest), stable
+//   nrm_sorted[n]  : 3 doubles per sorted target point (point-to-plane only)
+//   cell_start[k]  : number of target points with key < k, for k in [0, ncell]  (dense, uint32)
+// A cell is a cube of side h >= max_correspondence_distance*(1+1e-5), so every target point within the search
+// radius of a query lies in the 3x3x3 block around the query's cell.  Each x-row is padded by one empty cell on
+// both ends, which makes the three x-neighbours of any cell ONE contiguous run of tgt_sorted:
+// [cell_start[k-1], cell_start[k+2]) -- 9 run look-ups per query instead of 27.
+#include <math.h>
+
+#include <algorithm>
+
+#include "o3d_internal.h"
+
+namespace {
+
+constexpr double kCellSlack = 1.0 + 1e-5;      // h = r * slack: covers float(r*r) round-up and floor() rounding
+constexpr uint64_t kMaxDenseCells = 1ull << 31;  // uint32 keys; dense table <= 8 GiB
+constexpr double kCellsPerPointBudget = 64.0;   // coarsen the grid when the dense table would dwarf the cloud
+
+struct Bounds6 {
+  double mn[3], mx[3];
+  unsigned long long finite;
+};
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d, O3D_WAVE));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, O3D_WAVE));
+  return v;
+}
+
+// K8: AABB of the finite points (Geometry3D::ComputeMinBound/MaxBound, geometry/Geometry3D.cpp:39-53).
+__global__ __launch_bounds__(O3D_BLOCK) void k_bounds_partial(const double *__restrict__ xyz, int64_t n, Bounds6 *__restrict__ part) {
+  __shared__ double s[O3D_BLOCK / O3D_WAVE][6];
+  __shared__ unsigned long long sc[O3D_BLOCK / O3D_WAVE];
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned long long cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      mn[0] = fmin(mn[0], x); mn[1] = fmin(mn[1], y); mn[2] = fmin(mn[2], z);
+      mx[0] = fmax(mx[0], x); mx[1] = fmax(mx[1], y); mx[2] = fmax(mx[2], z);
+      cnt++;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = wave_min(mn[d]);
+    mx[d] = wave_max(mx[d]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, O3D_WAVE);
+  if (lane == 0) {
+    for (int d = 0; d < 3; d++) { s[wave][d] = mn[d]; s[wave][3 + d] = mx[d]; }
+    sc[wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Bounds6 b;
+    for (int d = 0; d < 3; d++) { b.mn[d] = s[0][d]; b.mx[d] = s[0][3 + d]; }
+    b.finite = sc[0];
+    for (int w = 1; w < O3D_BLOCK / O3D_WAVE; w++) {
+      for (int d = 0; d < 3; d++) { b.mn[d] = fmin(b.mn[d], s[w][d]); b.mx[d] = fmax(b.mx[d], s[w][3 + d]); }
+      b.finite += sc[w];
+    }
+    part[blockIdx.x] = b;
+  }
+}
+
+__global__ void k_bounds_final(const Bounds6 *__restrict__ part, int nparts, Bounds6 *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Bounds6 b = part[0];
+  for (int p = 1; p < nparts; p++) {
+    for (int d = 0; d < 3; d++) { b.mn[d] = fmin(b.mn[d], part[p].mn[d]); b.mx[d] = fmax(b.mx[d], part[p].mx[d]); }
+    b.finite += part[p].finite;
+  }
+  *out = b;
+}
+
+// K1a: cell key per target point, + per-cell population count (histogram) in the dense table.
+// Non-finite points can never be a nearest neighbour (d2 is NaN or inf): they get the sentinel key ncell and
+// sort behind every real cell.
+__global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
+                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                            uint32_t *__restrict__ cell_count) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint32_t key = gp.ncell;
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+      int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+      int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+      key = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)(cx + 1);
+      atomicAdd(&cell_count[key], 1u);
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// K1c: gather the target into cell order (stable: ascending original index inside a cell).
+__global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__restrict__ xyz, const double *__restrict__ nrm,
+                                                              const uint32_t *__restrict__ vals, int64_t n_grid,
+                                                              double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const uint32_t i = vals[p];
+    double4 q;
+    q.x = xyz[3 * (size_t)i];
+    q.y = xyz[3 * (size_t)i + 1];
+    q.z = xyz[3 * (size_t)i + 2];
+    q.w = __longlong_as_double((long long)i);
+    tgt_sorted[p] = q;
+    if (nrm) {
+      nrm_sorted[3 * p] = nrm[3 * (size_t)i];
+      nrm_sorted[3 * p + 1] = nrm[3 * (size_t)i + 1];
+      nrm_sorted[3 * p + 2] = nrm[3 * (size_t)i + 2];
+    }
+  }
+}
+
+// Source ordering key: the target-grid cell of the (init-transformed) source point, clamped into the grid.
+// Only the processing ORDER depends on it (spatially coherent wavefronts); results are scattered back by index.
+__global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
+                                                            const double *__restrict__ T, int apply, uint32_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (apply) {
+      double tx = ((T[0] * x + T[4] * y) + T[8] * z) + T[12];
+      double ty = ((T[1] * x + T[5] * y) + T[9] * z) + T[13];
+      double tz = ((T[2] * x + T[6] * y) + T[10] * z) + T[14];
+      x = tx; y = ty; z = tz;
+    }
+    int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    keys[i] = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)(cx + 1);
+    vals[i] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_gather_source(const double *__restrict__ xyz, const uint32_t *__restrict__ vals,
+                                                              int64_t n, double *__restrict__ src_sorted) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const size_t i = vals[p];
+    src_sorted[3 * p] = xyz[3 * i];
+    src_sorted[3 * p + 1] = xyz[3 * i + 1];
+    src_sorted[3 * p + 2] = xyz[3 * i + 2];
+  }
+}
+
+int grid_for(int64_t n) {
+  int64_t g = (n + O3D_BLOCK - 1) / O3D_BLOCK;
+  if (g < 1) g = 1;
+  if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  return (int)g;
+}
+
+int ceil_log2(uint64_t v) {
+  int b = 0;
+  while ((1ull << b) < v) b++;
+  return b;
+}
+
+}  // namespace
+
+int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], int64_t *out_finite) {
+  const int g = grid_for(n);
+  void *buf;
+  O3D_TRY(o3d_scratch(ctx, 0, sizeof(Bounds6) * (size_t)(g + 1), &buf));
+  Bounds6 *part = (Bounds6 *)buf;
+  hipLaunchKernelGGL(k_bounds_partial, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, part);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, ctx->stream, part, g, part + g);
+  Bounds6 *h = (Bounds6 *)ctx->pinned;
+  O3D_HIP(ctx, hipMemcpyAsync(h, part + g, sizeof(Bounds6), hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int d = 0; d < 3; d++) { out6[d] = h->mn[d]; out6[3 + d] = h->mx[d]; }
+  *out_finite = (int64_t)h->finite;
+  return O3D_OK;
+}
+
+int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist) {
+  ctx->n_tgt = n;
+  ctx->n_tgt_grid = 0;
+  GridParams gp{};
+  gp.nx = gp.ny = gp.nz = 1;
+  gp.nxp = 3;
+  gp.h = max_dist * kCellSlack;
+  gp.inv_h = 1.0 / gp.h;
+  gp.ncell = 3;
+  double bb[6] = {0, 0, 0, 0, 0, 0};
+  int64_t nfinite = 0;
+  if (n > 0) O3D_TRY(o3d_bounds(ctx, dev_xyz, n, bb, &nfinite));
+  if (nfinite > 0) {
+    double h = max_dist * kCellSlack;
+    const double ext[3] = {bb[3] - bb[0], bb[4] - bb[1], bb[5] - bb[2]};
+    // Dense table budget: coarsen (h *= 1.25) until it fits; a coarser grid is still exact, only slower.
+    for (;;) {
+      double c[3];
+      double total = 1.0;
+      for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0;
+      total = (c[0] + 2.0) * c[1] * c[2];
+      const double budget = std::max(kCellsPerPointBudget * (double)nfinite, 16777216.0);
+      if (total < (double)kMaxDenseCells && total <= budget) {
+        gp.nx = (int)c[0]; gp.ny = (int)c[1]; gp.nz = (int)c[2];
+        break;
+      }
+      h *= 1.25;
+    }
+    gp.h = h;
+    gp.inv_h = 1.0 / h;
+    for (int d = 0; d < 3; d++) gp.gmin[d] = bb[d];
+    gp.nxp = gp.nx + 2;
+    gp.ncell = (uint32_t)((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz);
+  }
+  ctx->gp = gp;
+
+  // dense table: ncell + 1 prefix entries (+1 sentinel bucket for non-finite points), padded for uint4 access
+  const size_t ntab = (size_t)gp.ncell + 2;
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->cell_start, &ctx->cap_cells, sizeof(uint32_t) * (ntab + 8)));
+  O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (ntab + 8), ctx->stream));
+  if (n <= 0) return O3D_OK;
+
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
+  if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
+
+  const size_t ntiles = o3d_sort_num_tiles(n);
+  const size_t nh = 256 * ntiles;
+  void *keys, *vals, *tkeys, *tvals, *hist, *bsum;
+  O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
+  O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
+  O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
+  O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
+  O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+  O3D_TRY(o3d_scratch(ctx, 6, sizeof(uint32_t) * (o3d_scan_num_blocks((int64_t)ntab) + 8), &bsum));
+
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint32_t *)keys,
+                     (uint32_t *)vals, ctx->cell_start);
+  O3D_TRY(o3d_exclusive_scan_u32(ctx, ctx->cell_start, (uint32_t *)bsum, (int64_t)ntab));
+  O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
+                             n, ceil_log2((uint64_t)gp.ncell + 1)));
+  ctx->n_tgt_grid = nfinite;
+  if (nfinite > 0)
+    hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
+                       (const uint32_t *)vals, nfinite, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double *init_colmajor, int apply_init) {
+  ctx->n_src = n;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  if (nn > ctx->cap_src) {
+    if (ctx->src_sorted) (void)hipFree(ctx->src_sorted);
+    if (ctx->src_perm) (void)hipFree(ctx->src_perm);
+    if (ctx->corr_sorted) (void)hipFree(ctx->corr_sorted);
+    if (ctx->corr_out) (void)hipFree(ctx->corr_out);
+    ctx->src_sorted = nullptr; ctx->src_perm = nullptr; ctx->corr_sorted = nullptr; ctx->corr_out = nullptr;
+    ctx->cap_src = 0;
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->src_sorted, sizeof(double) * 3 * nn));
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->src_perm, sizeof(uint32_t) * nn));
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_sorted, sizeof(int32_t) * nn));
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_out, sizeof(int32_t) * nn));
+    ctx->cap_src = nn;
+  }
+  if (n <= 0) return O3D_OK;
+  const size_t ntiles = o3d_sort_num_tiles(n);
+  const size_t nh = 256 * ntiles;
+  void *keys, *tkeys, *tvals, *hist, *dT;
+  O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
+  O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
+  O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
+  O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+  O3D_TRY(o3d_scratch(ctx, 7, sizeof(double) * 16, &dT));
+  double *hT = (double *)ctx->pinned + 64;
+  for (int i = 0; i < 16; i++) hT[i] = init_colmajor[i];
+  O3D_HIP(ctx, hipMemcpyAsync(dT, hT, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream));
+  const int g = grid_for(n);
+  hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, (const double *)dT,
+                     apply_init, (uint32_t *)keys, ctx->src_perm);
+  O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, ctx->src_perm, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
+                             ceil_log2((uint64_t)ctx->gp.ncell + 1)));
+  hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
+                     ctx->src_sorted);
+  O3D_HIP(ctx, hipGetLastError());
+  // the pinned staging for T must stay valid until the copy has run
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}

@@ -1,0 +1,456 @@
+// The ICP iteration on the device.
+//
+//   k_icp_pass      one fused per-source-point kernel: pending update applied in place (Geometry3D.cpp:77-82), exact
+//                   radius-bounded nearest neighbour over the cell grid (KDTreeFlann::SearchHybrid with max_nn = 1,
+//                   geometry/KDTreeFlann.cpp:132-152, as used by Registration.cpp:60-68), correspondence index out, and
+//                   the per-thread fp64 accumulation of the NEXT estimate's sums (utility/Eigen.cpp:180-185 with the
+//                   lambda of TransformationEstimation.cpp:79-86, or the Umeyama moments of :53-59), reduced by wavefront
+//                   shuffles and an LDS tree to one 32-double partial per workgroup.
+//   k_icp_finalize  fixed-order sum of the workgroup partials -> this shard's 32 sums (run-to-run deterministic).
+//   k_icp_solve     one lane: sum over ranks in rank order, fitness / rmse (Registration.cpp:82-89), convergence test
+//                   (:162-165), 6x6 pivoted LDLT (utility/Eigen.cpp:85,116-130) or Umeyama + 3x3 Jacobi SVD, Rz*Ry*Rx
+//                   (utility/Eigen.cpp:89-97), transformation = update * transformation (:158).
+//
+// Bit-exactness of the correspondence search: d2 = ((dx*dx)+dy*dy)+dz*dz with separate IEEE multiplies and adds (this
+// file is compiled with -ffp-contract=off), accept iff d2 < (double)(float)(r*r), argmin over (d2, target index).
+#include <math.h>
+
+#include "o3d_internal.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, O3D_WAVE);
+  return v;
+}
+
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src, int64_t n_src, const double4 *__restrict__ tgt,
+                                                         const double *__restrict__ nrm, const uint32_t *__restrict__ cell_start,
+                                                         GridParams gp, double thr, const IcpState *__restrict__ st,
+                                                         int32_t *__restrict__ corr, double *__restrict__ partials) {
+  if (st->done) return;
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  const int apply = st->apply_update;
+  double T[12];  // rows 0..2 of the pending update (row r: T[r], T[3+r]... stored column-major below)
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) T[c * 3 + r] = st->update[c * 4 + r];
+  const double w0 = st->update[3], w1 = st->update[7], w2 = st->update[11], w3 = st->update[15];
+  const double cx0 = st->centre[0], cy0 = st->centre[1], cz0 = st->centre[2];
+
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+
+  // contiguous chunk of the (cell-ordered) source per workgroup
+  const int64_t per = ((n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
+  const int64_t beg = (int64_t)blockIdx.x * per;
+  const int64_t end = beg + per < n_src ? beg + per : n_src;
+
+  for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
+    double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+    if (apply) {
+      // Eigen 4x4 * [p;1], then divide by w (Geometry3D.cpp:79-80)
+      double nx_ = ((T[0] * x + T[3] * y) + T[6] * z) + T[9];
+      double ny_ = ((T[1] * x + T[4] * y) + T[7] * z) + T[10];
+      double nz_ = ((T[2] * x + T[5] * y) + T[8] * z) + T[11];
+      double nw_ = ((w0 * x + w1 * y) + w2 * z) + w3;
+      x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
+      src[3 * i] = x; src[3 * i + 1] = y; src[3 * i + 2] = z;
+    }
+    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
+    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
+    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
+    const int lo = max(cx - 1, -1), hi = min(cx + 1, gp.nx);
+
+    double best = thr;
+    long long best_idx = -1;
+    uint32_t best_pos = 0;
+    double bx = 0, by = 0, bz = 0;
+    if (lo <= hi) {
+      for (int dz = -1; dz <= 1; dz++) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= gp.nz) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= gp.ny) continue;
+          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+          const uint32_t s = cell_start[row + (uint32_t)(lo + 1)];
+          const uint32_t e = cell_start[row + (uint32_t)(hi + 2)];
+          for (uint32_t j = s; j < e; j++) {
+            const double4 p = tgt[j];
+            const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+            double d2 = ddx * ddx;
+            d2 = d2 + ddy * ddy;
+            d2 = d2 + ddz * ddz;
+            const long long id = __double_as_longlong(p.w);
+            if (d2 < best || (d2 == best && id < best_idx)) {
+              best = d2; best_idx = id; best_pos = j;
+              bx = p.x; by = p.y; bz = p.z;
+            }
+          }
+        }
+      }
+    }
+    corr[i] = (int32_t)best_idx;
+    if (best_idx >= 0) {
+      if (EST == O3D_EST_POINT_TO_PLANE) {
+        const double n0 = nrm[3 * (size_t)best_pos], n1 = nrm[3 * (size_t)best_pos + 1], n2 = nrm[3 * (size_t)best_pos + 2];
+        double r = (x - bx) * n0;
+        r = r + (y - by) * n1;
+        r = r + (z - bz) * n2;
+        double J[6];
+        J[0] = y * n2 - z * n1;
+        J[1] = z * n0 - x * n2;
+        J[2] = x * n1 - y * n0;
+        J[3] = n0; J[4] = n1; J[5] = n2;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = a; b < 6; b++) acc[k++] += J[a] * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += J[a] * r;
+        acc[27] += r * r;
+      } else {
+        const double sx = x - cx0, sy = y - cy0, sz = z - cz0;
+        const double tx = bx - cx0, ty = by - cy0, tz = bz - cz0;
+        acc[0] += sx; acc[1] += sy; acc[2] += sz;
+        acc[3] += tx; acc[4] += ty; acc[5] += tz;
+        acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
+        acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
+        acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
+        acc[15] += (sx * sx + sy * sy) + sz * sz;
+      }
+      acc[O3D_SUM_D2] += best;
+      acc[O3D_SUM_NC] += 1.0;
+    }
+  }
+
+  // wavefront shuffle reduction, then a fixed-order LDS combine across the four waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 30; k++) {
+    double v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < O3D_NSUMS) {
+    double v = 0.0;
+    if (threadIdx.x < 30) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    partials[(size_t)blockIdx.x * O3D_NSUMS + threadIdx.x] = v;
+  }
+}
+
+// Fixed-order reduction of the workgroup partials.  256 threads: thread (g, k) sums partials[b][k] for b = g, g+8, ...
+// and the eight group sums are added in group order.
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_finalize(const double *__restrict__ partials, int nparts,
+                                                             const IcpState *__restrict__ st, double *__restrict__ sums) {
+  if (st->done) return;
+  __shared__ double s[8][O3D_NSUMS];
+  const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double v = 0.0;
+  for (int b = g; b < nparts; b += 8) v += partials[(size_t)b * O3D_NSUMS + k];
+  s[g][k] = v;
+  __syncthreads();
+  if (threadIdx.x < O3D_NSUMS) {
+    double t = s[0][k];
+#pragma unroll
+    for (int q = 1; q < 8; q++) t += s[q][k];
+    sums[k] = t;
+  }
+}
+
+// ------------------------------------------------------------------ small dense algebra, one lane
+#define TM(T, r, c) ((T)[(c) * 4 + (r)])
+
+__device__ void mat4_identity(double *T) {
+  for (int i = 0; i < 16; i++) T[i] = 0.0;
+  T[0] = T[5] = T[10] = T[15] = 1.0;
+}
+
+__device__ void mat4_mul(const double *A, const double *B, double *C) {
+  double R[16];
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      double a = TM(A, r, 0) * TM(B, 0, c);
+      a = a + TM(A, r, 1) * TM(B, 1, c);
+      a = a + TM(A, r, 2) * TM(B, 2, c);
+      a = a + TM(A, r, 3) * TM(B, 3, c);
+      R[c * 4 + r] = a;
+    }
+  for (int i = 0; i < 16; i++) C[i] = R[i];
+}
+
+// x = A^-1 b by LDL^T with symmetric pivoting on the largest |diagonal| (Eigen::LDLT semantics, utility/Eigen.cpp:85):
+// lower triangle only, zero pivot -> zero component.
+__device__ void ldlt_solve6(const double *A, const double *b, double *x) {
+  const int n = 6;
+  double M[36];
+  int tr[6];
+  for (int i = 0; i < 36; i++) M[i] = A[i];
+#define MM(i, j) M[(i) * 6 + (j)]
+  for (int k = 0; k < n; k++) {
+    int p = k;
+    double big = fabs(MM(k, k));
+    for (int i = k + 1; i < n; i++)
+      if (fabs(MM(i, i)) > big) { big = fabs(MM(i, i)); p = i; }
+    tr[k] = p;
+    if (p != k) {
+      for (int j = 0; j < k; j++) { double t = MM(k, j); MM(k, j) = MM(p, j); MM(p, j) = t; }
+      for (int i = p + 1; i < n; i++) { double t = MM(i, k); MM(i, k) = MM(i, p); MM(i, p) = t; }
+      for (int i = k + 1; i < p; i++) { double t = MM(i, k); MM(i, k) = MM(p, i); MM(p, i) = t; }
+      double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t;
+    }
+    if (k > 0) {
+      double temp[6];
+      for (int j = 0; j < k; j++) temp[j] = MM(j, j) * MM(k, j);
+      double s = 0;
+      for (int j = 0; j < k; j++) s += MM(k, j) * temp[j];
+      MM(k, k) -= s;
+      for (int i = k + 1; i < n; i++) {
+        double a = 0;
+        for (int j = 0; j < k; j++) a += MM(i, j) * temp[j];
+        MM(i, k) -= a;
+      }
+    }
+    const double akk = MM(k, k);
+    if (fabs(akk) > 0)
+      for (int i = k + 1; i < n; i++) MM(i, k) /= akk;
+  }
+  double y[6];
+  for (int i = 0; i < n; i++) y[i] = b[i];
+  for (int k = 0; k < n; k++)
+    if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++) y[i] -= MM(i, j) * y[j];
+  for (int i = 0; i < n; i++) {
+    if (fabs(MM(i, i)) > 2.2250738585072014e-308) y[i] /= MM(i, i);
+    else y[i] = 0;
+  }
+  for (int i = n - 1; i >= 0; i--)
+    for (int j = i + 1; j < n; j++) y[i] -= MM(j, i) * y[j];
+  for (int k = n - 1; k >= 0; k--)
+    if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < n; i++) x[i] = y[i];
+#undef MM
+}
+
+__device__ void vec6_to_mat4(const double *v, double *T) {
+  const double sx = sin(v[0]), cx = cos(v[0]);
+  const double sy = sin(v[1]), cy = cos(v[1]);
+  const double sz = sin(v[2]), cz = cos(v[2]);
+  mat4_identity(T);
+  TM(T, 0, 0) = cy * cz;  TM(T, 0, 1) = sx * sy * cz - cx * sz;  TM(T, 0, 2) = cx * sy * cz + sx * sz;
+  TM(T, 1, 0) = cy * sz;  TM(T, 1, 1) = sx * sy * sz + cx * cz;  TM(T, 1, 2) = cx * sy * sz - sx * cz;
+  TM(T, 2, 0) = -sy;      TM(T, 2, 1) = sx * cy;                 TM(T, 2, 2) = cx * cy;
+  TM(T, 0, 3) = v[3]; TM(T, 1, 3) = v[4]; TM(T, 2, 3) = v[5];
+}
+
+__device__ void cross3(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ double det3(const double *M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// A = U diag(S) V^T (row-major 3x3), one-sided Jacobi; singular values descending.
+__device__ void svd3(const double *A, double *U, double *S, double *V) {
+  double W[9], Vm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; i++) W[i] = A[i];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 3; i++) {
+          alpha += W[i * 3 + p] * W[i * 3 + p];
+          beta += W[i * 3 + q] * W[i * 3 + q];
+          gamma += W[i * 3 + p] * W[i * 3 + q];
+        }
+        if (gamma == 0.0) continue;
+        if (gamma * gamma <= 1e-32 * alpha * beta) continue;
+        off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; i++) {
+          const double wp = W[i * 3 + p], wq = W[i * 3 + q];
+          W[i * 3 + p] = c * wp - s * wq;
+          W[i * 3 + q] = s * wp + c * wq;
+          const double vp = Vm[i * 3 + p], vq = Vm[i * 3 + q];
+          Vm[i * 3 + p] = c * vp - s * vq;
+          Vm[i * 3 + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sv[3];
+  for (int j = 0; j < 3; j++) sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+  int ord[3] = {0, 1, 2};
+  for (int a = 0; a < 2; a++)
+    for (int b = a + 1; b < 3; b++)
+      if (sv[ord[b]] > sv[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+  double Uc[3][3];
+  int have[3] = {0, 0, 0};
+  for (int j = 0; j < 3; j++) {
+    const int o = ord[j];
+    S[j] = sv[o];
+    for (int i = 0; i < 3; i++) V[i * 3 + j] = Vm[i * 3 + o];
+    if (sv[o] > 1e-300 && sv[o] > sv[ord[0]] * 1e-14) {
+      for (int i = 0; i < 3; i++) Uc[j][i] = W[i * 3 + o] / sv[o];
+      have[j] = 1;
+    }
+  }
+  if (!have[0]) { Uc[0][0] = 1; Uc[0][1] = 0; Uc[0][2] = 0; }
+  if (!have[1]) {
+    double e[3] = {0, 0, 0};
+    const double a0 = fabs(Uc[0][0]), a1 = fabs(Uc[0][1]), a2 = fabs(Uc[0][2]);
+    const int m = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
+    e[m] = 1;
+    double c[3];
+    cross3(Uc[0], e, c);
+    const double nrm = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int i = 0; i < 3; i++) Uc[1][i] = c[i] / nrm;
+  }
+  if (!have[2]) {
+    double c[3];
+    cross3(Uc[0], Uc[1], c);
+    const double nrm = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int i = 0; i < 3; i++) Uc[2][i] = c[i] / nrm;
+  }
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) U[i * 3 + j] = Uc[j][i];
+}
+
+// Eigen::umeyama from single-pass moments about a fixed origin c (TransformationEstimation.cpp:59):
+// mu_s = c + S_s/n, mu_d = c + S_d/n, sigma = S_ds/n - (S_d/n)(S_s/n)^T, var_s = S_ss/n - |S_s/n|^2.
+__device__ void umeyama_from_sums(const double *q, const double *centre, int with_scaling, double *T) {
+  const double n = q[O3D_SUM_NC];
+  const double inv_n = 1.0 / n;
+  double ms[3], md[3];
+  for (int d = 0; d < 3; d++) { ms[d] = q[d] * inv_n; md[d] = q[3 + d] * inv_n; }
+  double sig[9];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) sig[a * 3 + b] = q[6 + a * 3 + b] * inv_n - md[a] * ms[b];
+  const double var = q[15] * inv_n - (ms[0] * ms[0] + ms[1] * ms[1] + ms[2] * ms[2]);
+  double U[9], S[3], V[9];
+  svd3(sig, U, S, V);
+  double sgn[3] = {1, 1, 1};
+  if (det3(U) * det3(V) < 0) sgn[2] = -1;
+  double R[9];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += U[a * 3 + k] * sgn[k] * V[b * 3 + k];
+      R[a * 3 + b] = acc;
+    }
+  double c = 1.0;
+  if (with_scaling) c = 1.0 / var * (S[0] * sgn[0] + S[1] * sgn[1] + S[2] * sgn[2]);
+  mat4_identity(T);
+  for (int a = 0; a < 3; a++) {
+    const double mus[3] = {ms[0] + centre[0], ms[1] + centre[1], ms[2] + centre[2]};
+    const double rm = R[a * 3] * mus[0] + R[a * 3 + 1] * mus[1] + R[a * 3 + 2] * mus[2];
+    TM(T, a, 3) = (md[a] + centre[a]) - c * rm;
+    for (int b = 0; b < 3; b++) TM(T, a, b) = c * R[a * 3 + b];
+  }
+}
+
+__global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict__ all_sums, int n_ranks, int has_normals,
+                            double *__restrict__ log, int log_rows) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->done) return;
+  double q[O3D_NSUMS];
+  for (int k = 0; k < O3D_NSUMS; k++) {
+    double v = all_sums[k];
+    for (int r = 1; r < n_ranks; r++) v += all_sums[(size_t)r * O3D_NSUMS + k];
+    q[k] = v;
+  }
+  const double nc = q[O3D_SUM_NC];
+  double fit = 0.0, rmse = 0.0;
+  if (nc > 0.0) {  // Registration.cpp:82-89
+    fit = nc / st->n_src_global;
+    rmse = sqrt(q[O3D_SUM_D2] / nc);
+  }
+  const int pass = st->passes;
+  const double pf = st->fitness, pr = st->rmse;
+  st->fitness = fit; st->rmse = rmse; st->n_corr = nc; st->sum_d2 = q[O3D_SUM_D2];
+  st->passes = pass + 1;
+  if (log && pass < log_rows) {
+    double *L = log + (size_t)pass * O3D_LOG_STRIDE;
+    L[0] = fit; L[1] = rmse; L[2] = nc; L[3] = q[O3D_SUM_D2];
+    for (int i = 0; i < 16; i++) L[4 + i] = st->T[i];
+    for (int i = 0; i < O3D_NSUMS; i++) L[20 + i] = q[i];
+  }
+  if (pass >= 1) {
+    st->iters = pass;
+    if (fabs(pf - fit) < st->rel_fitness && fabs(pr - rmse) < st->rel_rmse) { st->done = 1; return; }  // :162-165
+  }
+  if (pass >= st->max_iter) { st->done = 1; return; }
+
+  double upd[16];
+  mat4_identity(upd);
+  if (nc > 0.0) {
+    if (st->estimation == O3D_EST_POINT_TO_PLANE) {
+      if (has_normals) {
+        double A[36], b[6], x[6];
+        int k = 0;
+        for (int a = 0; a < 6; a++)
+          for (int c = a; c < 6; c++) { A[a * 6 + c] = q[k]; A[c * 6 + a] = q[k]; k++; }
+        for (int a = 0; a < 6; a++) b[a] = -q[21 + a];
+        ldlt_solve6(A, b, x);
+        vec6_to_mat4(x, upd);
+      }
+    } else {
+      umeyama_from_sums(q, st->centre, st->with_scaling, upd);
+    }
+  }
+  for (int i = 0; i < 16; i++) st->update[i] = upd[i];
+  mat4_mul(upd, st->T, st->T);
+  st->apply_update = 1;
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__restrict__ corr_sorted, const uint32_t *__restrict__ perm,
+                                                             int64_t n, int32_t *__restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK)
+    out[perm[p]] = corr_sorted[p];
+}
+
+}  // namespace
+
+int o3d_launch_pass(o3d_ctx *ctx) {
+  const int g = ctx->pass_grid;
+  if (ctx->estimation == O3D_EST_POINT_TO_PLANE)
+    hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
+                       ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
+                       ctx->partials);
+  else
+    hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
+                       ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
+                       ctx->partials);
+  hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_BLOCK), 0, ctx->stream, ctx->partials, g, ctx->state, ctx->sums);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks) {
+  hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, ctx->state, dev_all_sums, n_ranks,
+                     ctx->nrm_sorted != nullptr ? 1 : 0, ctx->log, ctx->log_rows);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out) {
+  if (ctx->n_src <= 0) return O3D_OK;
+  int64_t g = (ctx->n_src + O3D_BLOCK - 1) / O3D_BLOCK;
+  if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  hipLaunchKernelGGL(k_scatter_corr, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->corr_sorted, ctx->src_perm, ctx->n_src,
+                     dev_out);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}

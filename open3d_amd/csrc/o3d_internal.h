@@ -1,0 +1,141 @@
+// Internal declarations shared by the HIP translation units of libo3d_amd.so.
+// gfx950 (MI355X / CDNA4) only: wave = 64, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/o3d_icp.h"
+
+#define O3D_WAVE 64
+#define O3D_BLOCK 256
+#define O3D_NUM_CU 256
+#define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
+#define O3D_NSUMS 32
+
+// ---- sums layout (per pass, fp64) -------------------------------------------
+// point-to-plane: [0..20] JTJ upper triangle row-major, [21..26] JTr, [27] sum r^2
+// point-to-point: [0..2] sum (s-c), [3..5] sum (t-c), [6..14] sum (t-c)(s-c)^T row-major, [15] sum |s-c|^2
+// both:           [28] sum d^2, [29] number of correspondences, [30..31] unused
+#define O3D_SUM_D2 28
+#define O3D_SUM_NC 29
+
+struct GridParams {
+  double gmin[3];  // grid origin (min of finite target points)
+  double inv_h;    // 1 / cell size
+  double h;
+  int nx, ny, nz;  // cells per axis (unpadded)
+  int nxp;         // padded row length = nx + 2 (one empty cell either side of every x-row)
+  uint32_t ncell;  // nxp * ny * nz
+};
+
+// Device-resident ICP state: everything the loop of Registration.cpp:146-167 carries between iterations.
+struct IcpState {
+  double T[16];       // cumulative transformation, column-major
+  double update[16];  // pending update for the next pass, column-major
+  double fitness, rmse, n_corr, sum_d2;
+  double rel_fitness, rel_rmse;
+  double centre[3];   // fixed origin subtracted inside the Umeyama sums
+  double n_src_global;
+  int max_iter;
+  int passes;        // LOOP-A passes completed
+  int iters;         // estimation updates applied
+  int done;          // loop ended (break or max_iteration)
+  int apply_update;  // next pass transforms the source by `update`
+  int estimation;
+  int with_scaling;
+  int pad;
+};
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct o3d_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // target grid
+  GridParams gp{};
+  int64_t n_tgt = 0;        // points given
+  int64_t n_tgt_grid = 0;   // finite points placed in the grid
+  double4 *tgt_sorted = nullptr;  // {x, y, z, bits(original index)} in cell order
+  double *nrm_sorted = nullptr;   // 3 doubles per sorted target point (nullable)
+  uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
+  size_t cap_tgt = 0, cap_nrm = 0, cap_cells = 0;
+
+  // source shard
+  int64_t n_src = 0;
+  double *src_sorted = nullptr;    // 3 doubles per point, processing order
+  uint32_t *src_perm = nullptr;    // processing position -> caller's index
+  int32_t *corr_sorted = nullptr;  // per processing position
+  int32_t *corr_out = nullptr;     // caller's order (device staging)
+  size_t cap_src = 0;
+
+  // loop
+  IcpState *state = nullptr;   // device
+  double *partials = nullptr;  // [grid][32]
+  double *sums = nullptr;      // [32] local
+  double *log = nullptr;       // [(max_iter+1)][O3D_LOG_STRIDE]
+  int log_rows = 0;
+  int pass_grid = 0;
+  int icp_ready = 0;
+  int max_iter = 0;
+  int enq_passes = 0;
+  int estimation = 0;
+  double thr = 0;  // (double)(float)(r*r)
+  double setup_ms[2] = {0, 0};
+
+  // generic scratch (sort buffers etc.)
+  void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  void *pinned = nullptr;  // 4 KiB pinned host staging
+};
+
+// ---- helpers ----------------------------------------------------------------
+int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...);
+#define O3D_HIP(ctx, call)                                                                        \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      return o3d_fail(ctx, e__ == hipErrorOutOfMemory ? O3D_ERR_OOM : O3D_ERR_HIP, "%s: %s (%s:%d)", #call, \
+                      hipGetErrorString(e__), __FILE__, __LINE__);                                \
+  } while (0)
+#define O3D_TRY(expr)          \
+  do {                         \
+    int s__ = (expr);          \
+    if (s__ != O3D_OK) return s__; \
+  } while (0)
+
+// grow-only device buffer
+int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes);
+int o3d_scratch(o3d_ctx *ctx, int slot, size_t bytes, void **out);
+
+// ---- sort_scan.hip ------------------------------------------------------------
+// Stable LSD radix sort of (key, value) pairs, 8 bits per pass over the low `bits` bits of the key.
+// keys/vals are overwritten with the sorted sequence (ping-pong through tmp buffers of the same size).
+// KeyT = uint32_t or uint64_t.  hist needs 256 * ntiles(n) uint32.
+size_t o3d_sort_num_tiles(int64_t n);
+int o3d_radix_sort_u32(o3d_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *tmp_keys, uint32_t *tmp_vals,
+                       uint32_t *hist, int64_t n, int bits);
+int o3d_radix_sort_u64(o3d_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *tmp_keys, uint32_t *tmp_vals,
+                       uint32_t *hist, int64_t n, int bits);
+// In-place exclusive prefix sum over n uint32 (n up to 2^31); block_sums needs ceil(n / 8192) + 1 uint32.
+size_t o3d_scan_num_blocks(int64_t n);
+int o3d_exclusive_scan_u32(o3d_ctx *ctx, uint32_t *data, uint32_t *block_sums, int64_t n);
+
+// ---- grid.hip -----------------------------------------------------------------
+int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist);
+int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double *init_colmajor, int apply_init);
+// AABB over finite points: out6 (host) = {minx,miny,minz,maxx,maxy,maxz}; *out_finite = number of finite points.
+int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], int64_t *out_finite);
+
+// ---- device helpers -------------------------------------------------------------
+__device__ __forceinline__ int o3d_cell_coord(double x, double gmin, double inv_h, int n) {
+  // monotone in x; NaN -> -2 (no neighbours); clamped to [-2, n+1]
+  double f = floor((x - gmin) * inv_h);
+  return (f >= -2.0) ? ((f <= (double)(n + 1)) ? (int)f : n + 1) : -2;
+}

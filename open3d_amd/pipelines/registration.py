@@ -1,0 +1,220 @@
+"""Host-side mirror of open3d::pipelines::registration (reference pipelines/registration/Registration.h:54-152,
+TransformationEstimation.h:43-130): same names, argument meaning, defaults and error behaviour; the work is done
+by libo3d_amd.so through the C ABI in include/o3d_icp.h."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..geometry import PointCloud
+
+
+class ICPConvergenceCriteria:
+    """Registration.h:54-76."""
+
+    def __init__(self, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30):
+        self.relative_fitness_ = float(relative_fitness)
+        self.relative_rmse_ = float(relative_rmse)
+        self.max_iteration_ = int(max_iteration)
+
+
+class RegistrationResult:
+    """Registration.h:107-126.  correspondence_set_ is an (n_corr, 2) int32 array of (source, target) pairs in
+    ascending source index (the reference's serial order)."""
+
+    def __init__(self, transformation=None):
+        self.transformation_ = np.eye(4) if transformation is None else np.array(transformation, dtype=np.float64)
+        self.correspondence_set_ = np.zeros((0, 2), np.int32)
+        self.inlier_rmse_ = 0.0
+        self.fitness_ = 0.0
+        self.iterations_ = 0  # extra: number of estimation updates applied
+        self.corr_ = None     # extra: dense int32[n_src] form (-1 = none)
+
+
+class TransformationEstimation:
+    def GetTransformationEstimationType(self):
+        raise NotImplementedError
+
+
+class TransformationEstimationPointToPoint(TransformationEstimation):
+    """TransformationEstimation.h:85-107 (with_scaling default false)."""
+
+    def __init__(self, with_scaling=False):
+        self.with_scaling_ = bool(with_scaling)
+
+    def GetTransformationEstimationType(self):
+        return _lib.EST_POINT_TO_POINT
+
+
+class TransformationEstimationPointToPlane(TransformationEstimation):
+    """TransformationEstimation.h:112-130."""
+    with_scaling_ = False
+
+    def GetTransformationEstimationType(self):
+        return _lib.EST_POINT_TO_PLANE
+
+
+def _pairs(corr):
+    idx = np.nonzero(corr >= 0)[0].astype(np.int32)
+    return np.stack([idx, corr[idx]], axis=1) if len(idx) else np.zeros((0, 2), np.int32)
+
+
+def RegistrationICP(source, target, max_correspondence_distance, init=None, estimation=None, criteria=None, ctx=None):
+    """RegistrationICP, Registration.cpp:129-168."""
+    ctx = ctx or _lib.default_context()
+    init = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+    estimation = estimation or TransformationEstimationPointToPoint(False)
+    criteria = criteria or ICPConvergenceCriteria()
+    est = estimation.GetTransformationEstimationType()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    nrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    T = np.zeros(16)
+    corr = np.empty(max(len(src), 1), np.int32)
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    iters = C.c_int()
+    ctx.check(ctx._lib.o3d_registration_icp(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), _lib.ptr(nrm), len(tgt),
+                                            float(max_correspondence_distance),
+                                            _lib.colmajor(init).ctypes.data_as(_lib.c_dp), est,
+                                            int(getattr(estimation, "with_scaling_", False)), criteria.relative_fitness_,
+                                            criteria.relative_rmse_, criteria.max_iteration_, _lib.MEM_HOST,
+                                            T.ctypes.data_as(_lib.c_dp), _lib.ptr(corr), C.byref(nc), C.byref(fit),
+                                            C.byref(rmse), C.byref(iters)))
+    res = RegistrationResult(_lib.from_colmajor(T))
+    res.corr_ = corr[: len(src)].copy()
+    res.correspondence_set_ = _pairs(res.corr_)
+    res.fitness_ = fit.value
+    res.inlier_rmse_ = rmse.value
+    res.iterations_ = iters.value
+    return res
+
+
+def EvaluateRegistration(source, target, max_correspondence_distance, transformation=None, ctx=None):
+    """EvaluateRegistration, Registration.cpp:118-127."""
+    ctx = ctx or _lib.default_context()
+    T = np.eye(4) if transformation is None else np.asarray(transformation, dtype=np.float64)
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    corr = np.empty(max(len(src), 1), np.int32)
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    ctx.check(ctx._lib.o3d_evaluate_registration(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), len(tgt),
+                                                 float(max_correspondence_distance),
+                                                 _lib.colmajor(T).ctypes.data_as(_lib.c_dp), _lib.MEM_HOST, _lib.ptr(corr),
+                                                 C.byref(nc), C.byref(fit), C.byref(rmse)))
+    res = RegistrationResult(T)
+    res.corr_ = corr[: len(src)].copy()
+    res.correspondence_set_ = _pairs(res.corr_)
+    res.fitness_ = fit.value
+    res.inlier_rmse_ = rmse.value
+    return res
+
+
+class IcpSession:
+    """Stepwise, device-resident form of the same loop (o3d_icp_setup / pass / solve / finish): the caller owns the
+    per-iteration exchange.  Buffers may be numpy arrays (host) or torch CUDA tensors (device, float64, contiguous)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self._keep = None
+        self.n_src = 0
+        self.max_iter = 0
+
+    def setup(self, src, tgt, tgt_normals, max_correspondence_distance, init=None, estimation=None, criteria=None,
+              n_src_global=None):
+        estimation = estimation or TransformationEstimationPointToPoint(False)
+        criteria = criteria or ICPConvergenceCriteria()
+        init = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+        on_device = hasattr(src, "data_ptr")
+        mem = _lib.MEM_DEVICE if on_device else _lib.MEM_HOST
+        if not on_device:
+            src = np.ascontiguousarray(src, dtype=np.float64)
+            tgt = np.ascontiguousarray(tgt, dtype=np.float64)
+            tgt_normals = np.ascontiguousarray(tgt_normals, dtype=np.float64) if tgt_normals is not None else None
+        self._keep = (src, tgt, tgt_normals)
+        self.n_src = int(src.shape[0])
+        self.max_iter = criteria.max_iteration_
+        self.mem = mem
+        c = self.ctx
+        c.check(c._lib.o3d_icp_setup(c.handle, _lib.ptr(src), self.n_src, _lib.ptr(tgt), _lib.ptr(tgt_normals),
+                                     int(tgt.shape[0]), float(max_correspondence_distance),
+                                     _lib.colmajor(init).ctypes.data_as(_lib.c_dp),
+                                     estimation.GetTransformationEstimationType(),
+                                     int(getattr(estimation, "with_scaling_", False)), criteria.relative_fitness_,
+                                     criteria.relative_rmse_, criteria.max_iteration_, mem,
+                                     int(n_src_global if n_src_global is not None else self.n_src)))
+        return self
+
+    def enqueue_pass(self):
+        c = self.ctx
+        c.check(c._lib.o3d_icp_pass(c.handle))
+
+    def local_sums_ptr(self):
+        return self.ctx._lib.o3d_icp_local_sums(self.ctx.handle)
+
+    def enqueue_solve(self, all_sums_ptr=None, n_ranks=1):
+        c = self.ctx
+        p = all_sums_ptr if all_sums_ptr is not None else self.local_sums_ptr()
+        c.check(c._lib.o3d_icp_solve(c.handle, C.c_void_p(p), int(n_ranks)))
+
+    def poll(self):
+        c = self.ctx
+        done, passes = C.c_int(), C.c_int()
+        c.check(c._lib.o3d_icp_poll(c.handle, C.byref(done), C.byref(passes)))
+        return bool(done.value), passes.value
+
+    def finish(self, want_corr=True, corr_out=None):
+        c = self.ctx
+        T = np.zeros(16)
+        nc = C.c_int64()
+        fit, rmse = C.c_double(), C.c_double()
+        iters = C.c_int()
+        corr = None
+        mem = _lib.MEM_HOST
+        if corr_out is not None:
+            corr, mem = corr_out, (_lib.MEM_DEVICE if hasattr(corr_out, "data_ptr") else _lib.MEM_HOST)
+        elif want_corr:
+            corr = np.empty(max(self.n_src, 1), np.int32)
+        c.check(c._lib.o3d_icp_finish(c.handle, mem, T.ctypes.data_as(_lib.c_dp), _lib.ptr(corr), C.byref(nc), C.byref(fit),
+                                      C.byref(rmse), C.byref(iters)))
+        res = RegistrationResult(_lib.from_colmajor(T))
+        if corr is not None and not hasattr(corr, "data_ptr"):
+            res.corr_ = corr[: self.n_src].copy()
+            res.correspondence_set_ = _pairs(res.corr_)
+        else:
+            res.corr_ = corr
+        res.fitness_ = fit.value
+        res.inlier_rmse_ = rmse.value
+        res.iterations_ = iters.value
+        res.n_corr_ = nc.value
+        return res
+
+    def log(self):
+        """Per-pass history rows {fitness, rmse, n_corr, sum_d2, T[16] col-major, sums[32]}."""
+        c = self.ctx
+        buf = np.zeros((self.max_iter + 1, _lib.LOG_STRIDE))
+        rows = C.c_int()
+        c.check(c._lib.o3d_icp_get_log(c.handle, buf.ctypes.data_as(_lib.c_dp), self.max_iter + 1, C.byref(rows)))
+        return buf[: rows.value]
+
+    def setup_ms(self):
+        c = self.ctx
+        ms = np.zeros(2)
+        c.check(c._lib.o3d_icp_get_setup_ms(c.handle, ms.ctypes.data_as(_lib.c_dp)))
+        return ms
+
+    def run(self, check_every=6):
+        """Single-GPU loop: Registration.cpp:154-166."""
+        self.enqueue_pass()
+        self.enqueue_solve()
+        it = 0
+        while it < self.max_iter:
+            upto = min(it + check_every, self.max_iter)
+            while it < upto:
+                self.enqueue_pass()
+                self.enqueue_solve()
+                it += 1
+            if it < self.max_iter and self.poll()[0]:
+                break
+        return self

@@ -1,0 +1,279 @@
+"""ctypes front-end of the CPU oracle (oracle/o3d_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (open3d_amd/) never imports it.
+Parity status: "parity unpinned" by the reference's own tests (it has none);
+see the header of o3d_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    """Compile liboracle.so / liboracle_serial.so with gcc (oracle/Makefile)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "o3d_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+
+
+def lib(serial=False):
+    name = "liboracle_serial.so" if serial else "liboracle.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_radius_threshold.restype = C.c_double
+        L.orc_radius_threshold.argtypes = [C.c_double]
+        L.orc_kdtree_build.restype = C.c_void_p
+        L.orc_kdtree_build.argtypes = [c_dp, C.c_int64]
+        L.orc_kdtree_free.argtypes = [C.c_void_p]
+        L.orc_compute_rmse.restype = C.c_double
+        L.orc_voxel_down_sample.restype = C.c_int64
+        _LIBS[name] = L
+    return _LIBS[name]
+
+
+def _d(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(c_ip)
+
+
+def _pts(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    assert a.ndim == 2 and a.shape[1] == 3
+    return a
+
+
+def _mat(T):
+    """numpy 4x4 (row-major view) -> column-major flat (Eigen::Matrix4d storage)."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float64).T).reshape(16)
+
+
+def _unmat(flat):
+    return np.array(flat, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def radius_threshold(r):
+    return lib().orc_radius_threshold(float(r))
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return lib().orc_max_threads()
+
+
+def correspondences(src, tgt, max_dist, brute=False):
+    """Registration.cpp:41-91 -> (corr int32[ns], n_corr, sum_d2, fitness, rmse)."""
+    L = lib()
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.empty(len(src), np.int32)
+    nc = C.c_int64()
+    sd2, fit, rmse = C.c_double(), C.c_double(), C.c_double()
+    kd = None if brute or len(tgt) == 0 else L.orc_kdtree_build(_d(tgt), len(tgt))
+    L.orc_correspondences(_d(src), C.c_int64(len(src)), _d(tgt), C.c_int64(len(tgt)), C.c_void_p(kd),
+                          C.c_double(max_dist), int(brute or kd is None), _i(corr), C.byref(nc), C.byref(sd2),
+                          C.byref(fit), C.byref(rmse))
+    if kd:
+        L.orc_kdtree_free(kd)
+    return corr, nc.value, sd2.value, fit.value, rmse.value
+
+
+def transform_points(T, pts):
+    out = _pts(pts).copy()
+    lib().orc_transform_points(_d(_mat(T)), _d(out), C.c_int64(len(out)))
+    return out
+
+
+def p2plane_compute(src, tgt, nrm, corr):
+    """TransformationEstimation.cpp:74-98 -> (T 4x4, JTJ 6x6, JTr 6, r2)."""
+    src, tgt, nrm = _pts(src), _pts(tgt), _pts(nrm)
+    corr = np.ascontiguousarray(corr, np.int32)
+    T = np.zeros(16)
+    JTJ = np.zeros(36)
+    JTr = np.zeros(6)
+    r2 = C.c_double()
+    lib().orc_p2plane_compute(_d(src), _d(tgt), _d(nrm), _i(corr), C.c_int64(len(src)), _d(T), _d(JTJ), _d(JTr), C.byref(r2))
+    return _unmat(T), JTJ.reshape(6, 6), JTr, r2.value
+
+
+def p2p_compute(src, tgt, corr, with_scaling=False):
+    """TransformationEstimation.cpp:49-60 -> T 4x4."""
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, np.int32)
+    T = np.zeros(16)
+    lib().orc_p2p_compute(_d(src), _d(tgt), _i(corr), C.c_int64(len(src)), int(with_scaling), _d(T))
+    return _unmat(T)
+
+
+def compute_rmse(src, tgt, nrm, corr, est_type):
+    src, tgt = _pts(src), _pts(tgt)
+    corr = np.ascontiguousarray(corr, np.int32)
+    n = _d(_pts(nrm)) if nrm is not None else None
+    return lib().orc_compute_rmse(_d(src), _d(tgt), n, _i(corr), C.c_int64(len(src)), int(est_type))
+
+
+def ldlt_solve(A, b):
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(len(b))
+    lib().orc_ldlt_solve(len(b), _d(A), _d(b), _d(x))
+    return x
+
+
+def vec6_to_mat4(v):
+    v = np.ascontiguousarray(v, np.float64)
+    T = np.zeros(16)
+    lib().orc_vec6_to_mat4(_d(v), _d(T))
+    return _unmat(T)
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, np.float64)
+    U, S, V = np.zeros(9), np.zeros(3), np.zeros(9)
+    lib().orc_svd3(_d(A), _d(U), _d(S), _d(V))
+    return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def is_identity(T):
+    return bool(lib().orc_is_identity(_d(_mat(T))))
+
+
+class ICPResult:
+    pass
+
+
+def registration_icp(src, tgt, max_dist, init=None, est_type=1, tgt_normals=None, with_scaling=False,
+                     rel_fitness=1e-6, rel_rmse=1e-6, max_iter=30, brute=False, want_log=False, serial=False):
+    """Registration.cpp:129-168.  est_type 1 = PointToPoint, 2 = PointToPlane."""
+    L = lib(serial)
+    src, tgt = _pts(src), _pts(tgt)
+    init = np.eye(4) if init is None else init
+    nrm = _pts(tgt_normals) if tgt_normals is not None else None
+    T = np.zeros(16)
+    corr = np.empty(len(src), np.int32)
+    nc = C.c_int64()
+    fit, rmse, tl = C.c_double(), C.c_double(), C.c_double()
+    iters = C.c_int()
+    log = np.zeros((max_iter + 1, 20)) if want_log else None
+    rc = L.orc_registration_icp(_d(src), C.c_int64(len(src)), _d(tgt), _d(nrm) if nrm is not None else None,
+                                C.c_int64(len(tgt)), C.c_double(max_dist), _d(_mat(init)), int(est_type),
+                                int(with_scaling), C.c_double(rel_fitness), C.c_double(rel_rmse), int(max_iter),
+                                int(brute), _d(T), _i(corr), C.byref(nc), C.byref(fit), C.byref(rmse), C.byref(iters),
+                                _d(log) if want_log else None, C.byref(tl))
+    if rc == 1:
+        raise RuntimeError("[Open3D ERROR] Invalid max_correspondence_distance.")
+    if rc == 2:
+        raise RuntimeError("[Open3D ERROR] TransformationEstimationPointToPlane and TransformationEstimationColoredICP "
+                           "require pre-computed normal vectors for target PointCloud.")
+    r = ICPResult()
+    r.transformation = _unmat(T)
+    r.corr = corr
+    r.n_corr = nc.value
+    r.fitness = fit.value
+    r.inlier_rmse = rmse.value
+    r.iterations = iters.value
+    r.loop_seconds = tl.value
+    r.log = log[: iters.value + 1] if want_log else None
+    return r
+
+
+def evaluate_registration(src, tgt, max_dist, T=None, brute=False):
+    """Registration.cpp:118-127 -> (corr, n_corr, fitness, rmse)."""
+    L = lib()
+    src, tgt = _pts(src), _pts(tgt)
+    T = np.eye(4) if T is None else T
+    corr = np.empty(len(src), np.int32)
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    L.orc_evaluate_registration(_d(src), C.c_int64(len(src)), _d(tgt), C.c_int64(len(tgt)), C.c_double(max_dist),
+                                _d(_mat(T)), int(brute), _i(corr), C.byref(nc), C.byref(fit), C.byref(rmse))
+    return corr, nc.value, fit.value, rmse.value
+
+
+def information_matrix(src, tgt, max_dist, T, brute=False):
+    src, tgt = _pts(src), _pts(tgt)
+    G = np.zeros(36)
+    lib().orc_information_matrix(_d(src), C.c_int64(len(src)), _d(tgt), C.c_int64(len(tgt)), C.c_double(max_dist),
+                                 _d(_mat(T)), int(brute), _d(G))
+    return G.reshape(6, 6)
+
+
+def voxel_down_sample(pts, voxel, normals=None, colors=None):
+    """PointCloud.cpp:273-306 -> (points, normals|None, colors|None, voxel_index int32[M,3]); sorted by (z,y,x)."""
+    pts = _pts(pts)
+    n = len(pts)
+    nrm = _pts(normals) if normals is not None else None
+    col = _pts(colors) if colors is not None else None
+    op = np.empty((max(n, 1), 3))
+    on = np.empty((max(n, 1), 3)) if nrm is not None else None
+    oc = np.empty((max(n, 1), 3)) if col is not None else None
+    ov = np.empty((max(n, 1), 3), np.int32)
+    m = lib().orc_voxel_down_sample(_d(pts), _d(nrm) if nrm is not None else None, _d(col) if col is not None else None,
+                                    C.c_int64(n), C.c_double(voxel), _d(op), _d(on) if on is not None else None,
+                                    _d(oc) if oc is not None else None, _i(ov))
+    if m == -1:
+        raise RuntimeError("[Open3D ERROR] [VoxelDownSample] voxel_size <= 0.")
+    if m == -2:
+        raise RuntimeError("[Open3D ERROR] [VoxelDownSample] voxel_size is too small.")
+    return op[:m].copy(), (on[:m].copy() if on is not None else None), (oc[:m].copy() if oc is not None else None), ov[:m].copy()
+
+
+KNN, RADIUS, HYBRID = 0, 1, 2
+
+
+def estimate_normals(pts, search_type=KNN, knn=30, radius=0.0, normals=None, want_counts=False):
+    """EstimateNormals.cpp:320-351 -> normals [n,3] (and neighbour counts)."""
+    pts = _pts(pts)
+    n = len(pts)
+    has = normals is not None
+    out = _pts(normals).copy() if has else np.zeros((n, 3))
+    cnt = np.zeros(n, np.int32)
+    if n:
+        lib().orc_estimate_normals(_d(pts), C.c_int64(n), int(search_type), int(knn), C.c_double(radius), _d(out), int(has),
+                                   _i(cnt))
+    return (out, cnt) if want_counts else out
+
+
+def neighbors(pts, q, search_type=KNN, knn=30, radius=0.0, brute=False, cap=4096):
+    pts = _pts(pts)
+    q = np.ascontiguousarray(q, np.float64)
+    n_out = cap if search_type == RADIUS else max(knn, 1)
+    idx = np.zeros(n_out, np.int32)
+    d2 = np.zeros(n_out)
+    k = lib().orc_neighbors(_d(pts), C.c_int64(len(pts)), _d(q), int(search_type), int(knn), C.c_double(radius), int(brute),
+                            _i(idx), _d(d2), int(cap))
+    k = min(k, n_out)
+    return idx[:k].copy(), d2[:k].copy()
+
+
+def compute_normal(pts, indices):
+    pts = _pts(pts)
+    indices = np.ascontiguousarray(indices, np.int32)
+    nv = np.zeros(3)
+    cov = np.zeros(9)
+    lib().orc_compute_normal(_d(pts), _i(indices), len(indices), _d(nv), _d(cov))
+    return nv, cov.reshape(3, 3)
+
+
+def fast_eigen3x3(cov):
+    cov = np.ascontiguousarray(cov, np.float64)
+    nv = np.zeros(3)
+    lib().orc_fast_eigen3x3(_d(cov), _d(nv))
+    return nv

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    from open3d_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def make_scene(n_src, n_tgt, cfg_id=0, L=6.0, theta_deg=0.5, tau=(1.0, -0.7, 0.5), noise=0.1):
+    """Height-field pair with enough relief at small N (L fixed, spacing = L / sqrt(n_tgt))."""
+    from open3d_amd import synthetic
+    return synthetic.make_pair(n_src, n_tgt, cfg_id=cfg_id, theta_deg=theta_deg, tau_in_spacings=tau,
+                               noise_in_spacings=noise, L=L)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
