@@ -109,6 +109,9 @@ O3D_API int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
  * The 32 fp64 partial sums land in the device buffer returned by o3d_icp_local_sums(). */
 O3D_API int o3d_icp_pass(o3d_ctx *ctx);
 O3D_API double *o3d_icp_local_sums(o3d_ctx *ctx); /* device pointer, 32 doubles */
+/* Same pass, partial sums written to a caller-owned device buffer of 32 doubles (e.g. a torch tensor that is then
+ * all-gathered over RCCL). */
+O3D_API int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out);
 /* Enqueue the estimate: sums `n_ranks` x 32 doubles (device pointer, rank-major, added in rank order so every
  * rank gets bit-identical results), then fitness/rmse (Registration.cpp:82-89), the convergence test
  * (:162-165), the 6x6 LDLT solve or Umeyama SVD, update composition (:158).  Pass the pointer from
@@ -123,6 +126,11 @@ O3D_API int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_transformation[16],
 /* Per-pass history for parity tests: row p = {fitness, rmse, n_corr, sum_d2, T[16] colmajor, sums[32]} = 52 doubles. */
 #define O3D_LOG_STRIDE 52
 O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows);
+/* HIP-event timing of the dominant kernel (k_icp_pass) on the context's stream.  enable != 0: every following pass is
+ * bracketed by two events (at most 512 passes are kept).  o3d_icp_profile_read synchronises, returns the mean kernel
+ * duration in milliseconds over the recorded passes and their number, and clears the record. */
+O3D_API int o3d_icp_profile(o3d_ctx *ctx, int enable);
+O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count);
 /* Timing breakdown of the last setup (milliseconds, HIP events): [0] grid build, [1] source upload+sort. */
 O3D_API int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]);
 

@@ -9,7 +9,7 @@
 
 #include "o3d_internal.h"
 
-int o3d_launch_pass(o3d_ctx *ctx);
+int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
@@ -174,6 +174,8 @@ void o3d_ctx_destroy(o3d_ctx *c) {
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   for (int i = 0; i < 4; i++)
     if (ctx->stage.p[i]) (void)hipFree(ctx->stage.p[i]);
+  for (hipEvent_t e : ctx->prof_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -223,6 +225,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
 
   // loop state
   ctx->estimation = estimation;
+  ctx->has_tgt_normals = (estimation == O3D_EST_POINT_TO_PLANE) ? 1 : 0;
   ctx->thr = (double)(float)(max_dist * max_dist);  // geometry/KDTreeFlann.cpp:148
   ctx->max_iter = max_iter;
   int64_t g = (n_src + O3D_BLOCK - 1) / O3D_BLOCK;
@@ -266,7 +269,38 @@ int o3d_icp_pass(o3d_ctx *ctx) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
-  return o3d_launch_pass(ctx);
+  return o3d_launch_pass(ctx, ctx->sums);
+}
+
+int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out) {
+  if (!ctx || !dev_sums_out) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass_to before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  ctx->enq_passes++;
+  return o3d_launch_pass(ctx, dev_sums_out);
+}
+
+int o3d_icp_profile(o3d_ctx *ctx, int enable) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  ctx->prof_on = enable ? 1 : 0;
+  ctx->prof_n = 0;
+  return O3D_OK;
+}
+
+int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0;
+  for (int i = 0; i < ctx->prof_n; i++) {
+    float ms = 0;
+    O3D_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  if (out_mean_ms) *out_mean_ms = ctx->prof_n ? tot / ctx->prof_n : 0.0;
+  if (out_count) *out_count = ctx->prof_n;
+  ctx->prof_n = 0;
+  return O3D_OK;
 }
 
 double *o3d_icp_local_sums(o3d_ctx *ctx) { return ctx ? ctx->sums : nullptr; }

@@ -423,8 +423,14 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__res
 
 }  // namespace
 
-int o3d_launch_pass(o3d_ctx *ctx) {
+int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out) {
   const int g = ctx->pass_grid;
+  const bool prof = ctx->prof_on && ctx->prof_n < 512;
+  if (prof) {
+    for (int k = 0; k < 2; k++)
+      if (!ctx->prof_ev[2 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[2 * ctx->prof_n + k]));
+    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream));
+  }
   if (ctx->estimation == O3D_EST_POINT_TO_PLANE)
     hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
                        ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
@@ -433,14 +439,18 @@ int o3d_launch_pass(o3d_ctx *ctx) {
     hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
                        ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
                        ctx->partials);
-  hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_BLOCK), 0, ctx->stream, ctx->partials, g, ctx->state, ctx->sums);
+  if (prof) {
+    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream));
+    ctx->prof_n++;
+  }
+  hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_BLOCK), 0, ctx->stream, ctx->partials, g, ctx->state, dev_sums_out);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }
 
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks) {
   hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(64), 0, ctx->stream, ctx->state, dev_all_sums, n_ranks,
-                     ctx->nrm_sorted != nullptr ? 1 : 0, ctx->log, ctx->log_rows);
+                     ctx->has_tgt_normals, ctx->log, ctx->log_rows);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

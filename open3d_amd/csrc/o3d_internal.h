@@ -88,6 +88,11 @@ struct o3d_ctx {
   int estimation = 0;
   double thr = 0;  // (double)(float)(r*r)
   double setup_ms[2] = {0, 0};
+  int has_tgt_normals = 0;
+
+  // optional HIP-event profile of k_icp_pass
+  int prof_on = 0, prof_n = 0;
+  hipEvent_t prof_ev[1024] = {};
 
   // generic scratch (sort buffers etc.)
   void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

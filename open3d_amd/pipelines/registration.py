@@ -150,6 +150,21 @@ class IcpSession:
         c = self.ctx
         c.check(c._lib.o3d_icp_pass(c.handle))
 
+    def enqueue_pass_to(self, dev_sums_ptr):
+        c = self.ctx
+        c.check(c._lib.o3d_icp_pass_to(c.handle, C.c_void_p(dev_sums_ptr)))
+
+    def profile(self, enable=True):
+        c = self.ctx
+        c.check(c._lib.o3d_icp_profile(c.handle, int(enable)))
+
+    def profile_read(self):
+        """(mean k_icp_pass duration in ms, number of passes recorded) from HIP events on the launch stream."""
+        c = self.ctx
+        ms, n = C.c_double(), C.c_int()
+        c.check(c._lib.o3d_icp_profile_read(c.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def local_sums_ptr(self):
         return self.ctx._lib.o3d_icp_local_sums(self.ctx.handle)
 
