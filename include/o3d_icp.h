@@ -117,6 +117,9 @@ O3D_API int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out);
  * (:162-165), the 6x6 LDLT solve or Umeyama SVD, update composition (:158).  Pass the pointer from
  * o3d_icp_local_sums() and n_ranks = 1 when not sharded. */
 O3D_API int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
+/* Unsharded shortcut: o3d_icp_pass + o3d_icp_solve(local sums, 1) with the partial reduction and the estimate fused
+ * into one launch. */
+O3D_API int o3d_icp_step(o3d_ctx *ctx);
 /* Synchronise and report whether the loop has ended (converged or max_iteration reached). */
 O3D_API int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes);
 /* Synchronise and fetch the RegistrationResult (Registration.h:107-126).  out_corr (n_src entries, `mem` space, may be

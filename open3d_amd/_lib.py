@@ -36,6 +36,7 @@ _SIGNATURES = {
                                 C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64]),
     "o3d_icp_pass": (C.c_int, [C.c_void_p]),
     "o3d_icp_local_sums": (C.c_void_p, [C.c_void_p]),
+    "o3d_icp_step": (C.c_int, [C.c_void_p]),
     "o3d_icp_pass_to": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),

@@ -9,7 +9,7 @@
 
 #include "o3d_internal.h"
 
-int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out);
+int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
@@ -231,6 +231,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   int64_t g = (n_src + O3D_BLOCK - 1) / O3D_BLOCK;
   if (g < 1) g = 1;
   if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  g = (g + 7) / 8 * 8;  // k_icp_pass maps workgroup -> chunk per XCD (8 XCDs)
   ctx->pass_grid = (int)g;
   const int rows = max_iter + 1;
   if (rows > ctx->log_rows || !ctx->log) {
@@ -269,7 +270,7 @@ int o3d_icp_pass(o3d_ctx *ctx) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
-  return o3d_launch_pass(ctx, ctx->sums);
+  return o3d_launch_pass(ctx, ctx->sums, 0);
 }
 
 int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out) {
@@ -277,7 +278,15 @@ int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass_to before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
-  return o3d_launch_pass(ctx, dev_sums_out);
+  return o3d_launch_pass(ctx, dev_sums_out, 0);
+}
+
+int o3d_icp_step(o3d_ctx *ctx) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_step before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  ctx->enq_passes++;
+  return o3d_launch_pass(ctx, ctx->sums, 1);
 }
 
 int o3d_icp_profile(o3d_ctx *ctx, int enable) {
@@ -380,15 +389,11 @@ int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, con
   // Registration.cpp:154-166.  The whole loop is enqueued without host round trips; kernels past the break are
   // no-ops (IcpState::done).  The host looks at the flag every kChunk iterations to stop enqueueing early.
   const int kChunk = 6;
-  O3D_TRY(o3d_icp_pass(ctx));
-  O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
+  O3D_TRY(o3d_icp_step(ctx));
   int it = 0;
   while (it < max_iter) {
     const int upto = it + kChunk < max_iter ? it + kChunk : max_iter;
-    for (; it < upto; it++) {
-      O3D_TRY(o3d_icp_pass(ctx));
-      O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
-    }
+    for (; it < upto; it++) O3D_TRY(o3d_icp_step(ctx));
     if (it < max_iter) {
       int done = 0;
       O3D_TRY(o3d_icp_poll(ctx, &done, nullptr));
@@ -418,8 +423,7 @@ int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src
     return O3D_OK;
   }
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem, n_src));
-  O3D_TRY(o3d_icp_pass(ctx));
-  O3D_TRY(o3d_icp_solve(ctx, ctx->sums, 1));
+  O3D_TRY(o3d_icp_step(ctx));
   return o3d_icp_finish(ctx, mem, nullptr, out_corr, out_n_corr, out_fitness, out_rmse, nullptr);
 }
 

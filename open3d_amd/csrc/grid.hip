@@ -76,14 +76,38 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_bounds_partial(const double *__re
   }
 }
 
-__global__ void k_bounds_final(const Bounds6 *__restrict__ part, int nparts, Bounds6 *__restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Bounds6 b = part[0];
-  for (int p = 1; p < nparts; p++) {
-    for (int d = 0; d < 3; d++) { b.mn[d] = fmin(b.mn[d], part[p].mn[d]); b.mx[d] = fmax(b.mx[d], part[p].mx[d]); }
-    b.finite += part[p].finite;
+__global__ __launch_bounds__(O3D_BLOCK) void k_bounds_final(const Bounds6 *__restrict__ part, int nparts, Bounds6 *__restrict__ out) {
+  __shared__ double s[O3D_BLOCK / O3D_WAVE][6];
+  __shared__ unsigned long long sc[O3D_BLOCK / O3D_WAVE];
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned long long cnt = 0;
+  for (int p = threadIdx.x; p < nparts; p += O3D_BLOCK) {
+    for (int d = 0; d < 3; d++) { mn[d] = fmin(mn[d], part[p].mn[d]); mx[d] = fmax(mx[d], part[p].mx[d]); }
+    cnt += part[p].finite;
   }
-  *out = b;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = wave_min(mn[d]);
+    mx[d] = wave_max(mx[d]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, O3D_WAVE);
+  if (lane == 0) {
+    for (int d = 0; d < 3; d++) { s[wave][d] = mn[d]; s[wave][3 + d] = mx[d]; }
+    sc[wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Bounds6 b;
+    for (int d = 0; d < 3; d++) { b.mn[d] = s[0][d]; b.mx[d] = s[0][3 + d]; }
+    b.finite = sc[0];
+    for (int w = 1; w < O3D_BLOCK / O3D_WAVE; w++) {
+      for (int d = 0; d < 3; d++) { b.mn[d] = fmin(b.mn[d], s[w][d]); b.mx[d] = fmax(b.mx[d], s[w][3 + d]); }
+      b.finite += sc[w];
+    }
+    *out = b;
+  }
 }
 
 // K1a: cell key per target point, + per-cell population count (histogram) in the dense table.
@@ -127,10 +151,22 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
   }
 }
 
-// Source ordering key: the target-grid cell of the (init-transformed) source point, clamped into the grid.
-// Only the processing ORDER depends on it (spatially coherent wavefronts); results are scattered back by index.
+// Spread the low 21 bits of v so that bit i lands at bit 3*i.
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {
+  uint64_t x = v & 0x1fffffu;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+// Source ordering key: Morton (Z-order) code of the target-grid cell of the (init-transformed) source point, clamped
+// into the grid.  Only the processing ORDER depends on it -- a workgroup's 256 consecutive points form a compact
+// patch of cells, so its candidate reads hit L1/L2; results are scattered back by original index.
 __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            const double *__restrict__ T, int apply, uint32_t *__restrict__ keys,
+                                                            const double *__restrict__ T, int apply, uint64_t *__restrict__ keys,
                                                             uint32_t *__restrict__ vals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -143,7 +179,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restr
     int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    keys[i] = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)(cx + 1);
+    keys[i] = spread3((uint32_t)cx) | (spread3((uint32_t)cy) << 1) | (spread3((uint32_t)cz) << 2);
     vals[i] = (uint32_t)i;
   }
 }
@@ -179,7 +215,7 @@ int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], i
   O3D_TRY(o3d_scratch(ctx, 0, sizeof(Bounds6) * (size_t)(g + 1), &buf));
   Bounds6 *part = (Bounds6 *)buf;
   hipLaunchKernelGGL(k_bounds_partial, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, part);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, ctx->stream, part, g, part + g);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(O3D_BLOCK), 0, ctx->stream, part, g, part + g);
   Bounds6 *h = (Bounds6 *)ctx->pinned;
   O3D_HIP(ctx, hipMemcpyAsync(h, part + g, sizeof(Bounds6), hipMemcpyDeviceToHost, ctx->stream));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -277,8 +313,8 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   const size_t ntiles = o3d_sort_num_tiles(n);
   const size_t nh = 256 * ntiles;
   void *keys, *tkeys, *tvals, *hist, *dT;
-  O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
-  O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
+  O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint64_t) * (size_t)n, &keys));
+  O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
   O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
   O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
   O3D_TRY(o3d_scratch(ctx, 7, sizeof(double) * 16, &dT));
@@ -287,9 +323,10 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   O3D_HIP(ctx, hipMemcpyAsync(dT, hT, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream));
   const int g = grid_for(n);
   hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, (const double *)dT,
-                     apply_init, (uint32_t *)keys, ctx->src_perm);
-  O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, ctx->src_perm, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
-                             ceil_log2((uint64_t)ctx->gp.ncell + 1)));
+                     apply_init, (uint64_t *)keys, ctx->src_perm);
+  const int axis_bits = ceil_log2((uint64_t)std::max(std::max(ctx->gp.nx, ctx->gp.ny), ctx->gp.nz));
+  O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, ctx->src_perm, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
+                             std::min(63, 3 * (axis_bits < 1 ? 1 : axis_bits))));
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
                      ctx->src_sorted);
   O3D_HIP(ctx, hipGetLastError());

@@ -25,6 +25,126 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Running argmin over (d2, original index); ties -> lowest target index.
+struct Best {
+  double d2;
+  long long idx;
+  uint32_t pos;
+  double x, y, z;
+};
+
+__device__ __forceinline__ void consider(const double4 &p, uint32_t j, double x, double y, double z, Best &b) {
+  const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+  double d2 = ddx * ddx;
+  d2 = d2 + ddy * ddy;
+  d2 = d2 + ddz * ddz;
+  const long long id = __double_as_longlong(p.w);
+  if (d2 < b.d2 || (d2 == b.d2 && id < b.idx)) {
+    b.d2 = d2; b.idx = id; b.pos = j;
+    b.x = p.x; b.y = p.y; b.z = p.z;
+  }
+}
+
+// Scan tgt[s, e).  Four candidate loads are kept in flight per lane; indices past the end are clamped to the last
+// element (re-considering a candidate never changes the running argmin).
+__device__ __forceinline__ void scan_run(const double4 *__restrict__ tgt, uint32_t s, uint32_t e, double x, double y, double z,
+                                         Best &b) {
+  if (s >= e) return;
+  const uint32_t last = e - 1;
+  for (uint32_t j = s; j < e; j += 4) {
+    const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+    const double4 p0 = tgt[j], p1 = tgt[j1], p2 = tgt[j2], p3 = tgt[j3];
+    consider(p0, j, x, y, z, b);
+    consider(p1, j1, x, y, z, b);
+    consider(p2, j2, x, y, z, b);
+    consider(p3, j3, x, y, z, b);
+  }
+}
+
+// Exact nearest neighbour with d2 < thr over the 3x3x3 cell block around the query.
+// Inside the grid the block is searched centre cell first; every other cell (or x-run of cells) is visited only if a
+// conservative lower bound of its distance to the query does not exceed the best distance so far.  The bound is the
+// per-axis distance to the neighbouring cell's face, shrunk by a margin that dominates the rounding of the cell
+// assignment, so pruning never changes the result.  All cell-table reads of the block are issued up front so that
+// they overlap (one memory latency instead of nine).
+__device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const uint32_t *__restrict__ cell_start,
+                                          const GridParams &gp, double x, double y, double z, Best &b) {
+  const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
+  const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
+  const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
+  const bool inside = cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
+  if (inside) {
+    const uint32_t rowc = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx;
+    const uint32_t s0 = cell_start[rowc], s1 = cell_start[rowc + 1], s2 = cell_start[rowc + 2], s3 = cell_start[rowc + 3];
+    // centre column of the eight neighbouring rows (rows outside the grid read a clamped, valid address)
+    uint32_t rs1[8], rs2[8], rrow[8];
+    {
+      int k = 0;
+#pragma unroll
+      for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+          if (dz == 0 && dy == 0) continue;
+          const int zz = min(max(cz + dz, 0), gp.nz - 1), yy = min(max(cy + dy, 0), gp.ny - 1);
+          rrow[k] = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp + (uint32_t)cx;
+          rs1[k] = cell_start[rrow[k] + 1];
+          rs2[k] = cell_start[rrow[k] + 2];
+          k++;
+        }
+    }
+    scan_run(tgt, s1, s2, x, y, z, b);
+    const double h = gp.h;
+    const double rx = x - gp.gmin[0], ry = y - gp.gmin[1], rz = z - gp.gmin[2];
+    const double fx = rx - (double)cx * h, fy = ry - (double)cy * h, fz = rz - (double)cz * h;
+    const double mx = 1e-6 * h + 1e-14 * fabs(rx), my = 1e-6 * h + 1e-14 * fabs(ry), mz = 1e-6 * h + 1e-14 * fabs(rz);
+    double t;
+    t = fmax(fx - mx, 0.0); const double axm = t * t;
+    t = fmax(h - fx - mx, 0.0); const double axp = t * t;
+    t = fmax(fy - my, 0.0); const double aym = t * t;
+    t = fmax(h - fy - my, 0.0); const double ayp = t * t;
+    t = fmax(fz - mz, 0.0); const double azm = t * t;
+    t = fmax(h - fz - mz, 0.0); const double azp = t * t;
+    if (axm <= b.d2) scan_run(tgt, s0, s1, x, y, z, b);
+    if (axp <= b.d2) scan_run(tgt, s2, s3, x, y, z, b);
+    {
+      int k = 0;
+#pragma unroll
+      for (int dz = -1; dz <= 1; dz++) {
+        const double bz = dz < 0 ? azm : (dz > 0 ? azp : 0.0);
+        const int zz = cz + dz;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+          if (dz == 0 && dy == 0) continue;
+          const double byz = bz + (dy < 0 ? aym : (dy > 0 ? ayp : 0.0));
+          const int yy = cy + dy;
+          if (byz <= b.d2 && zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny) {
+            uint32_t s = rs1[k], e = rs2[k];
+            if (axm + byz <= b.d2) s = cell_start[rrow[k]];      // corner reach: widen the run to the left cell
+            if (axp + byz <= b.d2) e = cell_start[rrow[k] + 3];  // ... and to the right cell
+            scan_run(tgt, s, e, x, y, z, b);
+          }
+          k++;
+        }
+      }
+    }
+  } else {
+    // query outside the target's bounding grid (or NaN): plain 27-cell search, x-neighbours as one run
+    const int lo = max(cx - 1, -1), hi = min(cx + 1, gp.nx);
+    if (lo <= hi) {
+      for (int dz = -1; dz <= 1; dz++) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= gp.nz) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= gp.ny) continue;
+          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+          scan_run(tgt, cell_start[row + (uint32_t)(lo + 1)], cell_start[row + (uint32_t)(hi + 2)], x, y, z, b);
+        }
+      }
+    }
+  }
+}
+
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src, int64_t n_src, const double4 *__restrict__ tgt,
                                                          const double *__restrict__ nrm, const uint32_t *__restrict__ cell_start,
@@ -33,7 +153,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
   if (st->done) return;
   __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
   const int apply = st->apply_update;
-  double T[12];  // rows 0..2 of the pending update (row r: T[r], T[3+r]... stored column-major below)
+  double T[12];  // element (r, c) of the pending update at T[c * 3 + r]
 #pragma unroll
   for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -46,8 +166,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
   for (int k = 0; k < 30; k++) acc[k] = 0.0;
 
   // contiguous chunk of the (cell-ordered) source per workgroup
+  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the Morton
+  // order so that neighbouring patches meet in the same L2.  The launch grid is a multiple of 8.
   const int64_t per = ((n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
-  const int64_t beg = (int64_t)blockIdx.x * per;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t beg = (int64_t)chunk * per;
   const int64_t end = beg + per < n_src ? beg + per : n_src;
 
   for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
@@ -61,47 +184,16 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
       x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
       src[3 * i] = x; src[3 * i + 1] = y; src[3 * i + 2] = z;
     }
-    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
-    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
-    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
-    const int lo = max(cx - 1, -1), hi = min(cx + 1, gp.nx);
-
-    double best = thr;
-    long long best_idx = -1;
-    uint32_t best_pos = 0;
-    double bx = 0, by = 0, bz = 0;
-    if (lo <= hi) {
-      for (int dz = -1; dz <= 1; dz++) {
-        const int zz = cz + dz;
-        if (zz < 0 || zz >= gp.nz) continue;
-        for (int dy = -1; dy <= 1; dy++) {
-          const int yy = cy + dy;
-          if (yy < 0 || yy >= gp.ny) continue;
-          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-          const uint32_t s = cell_start[row + (uint32_t)(lo + 1)];
-          const uint32_t e = cell_start[row + (uint32_t)(hi + 2)];
-          for (uint32_t j = s; j < e; j++) {
-            const double4 p = tgt[j];
-            const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
-            double d2 = ddx * ddx;
-            d2 = d2 + ddy * ddy;
-            d2 = d2 + ddz * ddz;
-            const long long id = __double_as_longlong(p.w);
-            if (d2 < best || (d2 == best && id < best_idx)) {
-              best = d2; best_idx = id; best_pos = j;
-              bx = p.x; by = p.y; bz = p.z;
-            }
-          }
-        }
-      }
-    }
-    corr[i] = (int32_t)best_idx;
-    if (best_idx >= 0) {
+    Best b;
+    b.d2 = thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+    nn_search(tgt, cell_start, gp, x, y, z, b);
+    corr[i] = (int32_t)b.idx;
+    if (b.idx >= 0) {
       if (EST == O3D_EST_POINT_TO_PLANE) {
-        const double n0 = nrm[3 * (size_t)best_pos], n1 = nrm[3 * (size_t)best_pos + 1], n2 = nrm[3 * (size_t)best_pos + 2];
-        double r = (x - bx) * n0;
-        r = r + (y - by) * n1;
-        r = r + (z - bz) * n2;
+        const double n0 = nrm[3 * (size_t)b.pos], n1 = nrm[3 * (size_t)b.pos + 1], n2 = nrm[3 * (size_t)b.pos + 2];
+        double r = (x - b.x) * n0;
+        r = r + (y - b.y) * n1;
+        r = r + (z - b.z) * n2;
         double J[6];
         J[0] = y * n2 - z * n1;
         J[1] = z * n0 - x * n2;
@@ -111,13 +203,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
-          for (int b = a; b < 6; b++) acc[k++] += J[a] * J[b];
+          for (int c = a; c < 6; c++) acc[k++] += J[a] * J[c];
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[21 + a] += J[a] * r;
         acc[27] += r * r;
       } else {
         const double sx = x - cx0, sy = y - cy0, sz = z - cz0;
-        const double tx = bx - cx0, ty = by - cy0, tz = bz - cz0;
+        const double tx = b.x - cx0, ty = b.y - cy0, tz = b.z - cz0;
         acc[0] += sx; acc[1] += sy; acc[2] += sz;
         acc[3] += tx; acc[4] += ty; acc[5] += tz;
         acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
@@ -125,7 +217,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
         acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
         acc[15] += (sx * sx + sy * sy) + sz * sz;
       }
-      acc[O3D_SUM_D2] += best;
+      acc[O3D_SUM_D2] += b.d2;
       acc[O3D_SUM_NC] += 1.0;
     }
   }
@@ -141,27 +233,34 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
   if (threadIdx.x < O3D_NSUMS) {
     double v = 0.0;
     if (threadIdx.x < 30) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    partials[(size_t)blockIdx.x * O3D_NSUMS + threadIdx.x] = v;
+    partials[(size_t)chunk * O3D_NSUMS + threadIdx.x] = v;
   }
 }
 
-// Fixed-order reduction of the workgroup partials.  256 threads: thread (g, k) sums partials[b][k] for b = g, g+8, ...
-// and the eight group sums are added in group order.
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_finalize(const double *__restrict__ partials, int nparts,
-                                                             const IcpState *__restrict__ st, double *__restrict__ sums) {
-  if (st->done) return;
-  __shared__ double s[8][O3D_NSUMS];
+// Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
+// partials[b][k] for b = g, g + 32, ... (coalesced over k), the 32 group sums are then added in group order.
+#define O3D_FIN_THREADS 1024
+__device__ __forceinline__ void finalize_sums(const double *__restrict__ partials, int nparts, double (*s)[O3D_NSUMS]) {
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
   double v = 0.0;
-  for (int b = g; b < nparts; b += 8) v += partials[(size_t)b * O3D_NSUMS + k];
+  for (int b = g; b < nparts; b += 32) v += partials[(size_t)b * O3D_NSUMS + k];
   s[g][k] = v;
   __syncthreads();
   if (threadIdx.x < O3D_NSUMS) {
     double t = s[0][k];
 #pragma unroll
-    for (int q = 1; q < 8; q++) t += s[q][k];
-    sums[k] = t;
+    for (int q = 1; q < 32; q++) t += s[q][k];
+    s[0][k] = t;
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize(const double *__restrict__ partials, int nparts,
+                                                                   const IcpState *__restrict__ st, double *__restrict__ sums) {
+  if (st->done) return;
+  __shared__ double s[32][O3D_NSUMS];
+  finalize_sums(partials, nparts, s);
+  if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
 }
 
 // ------------------------------------------------------------------ small dense algebra, one lane
@@ -361,16 +460,8 @@ __device__ void umeyama_from_sums(const double *q, const double *centre, int wit
   }
 }
 
-__global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict__ all_sums, int n_ranks, int has_normals,
-                            double *__restrict__ log, int log_rows) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (st->done) return;
-  double q[O3D_NSUMS];
-  for (int k = 0; k < O3D_NSUMS; k++) {
-    double v = all_sums[k];
-    for (int r = 1; r < n_ranks; r++) v += all_sums[(size_t)r * O3D_NSUMS + k];
-    q[k] = v;
-  }
+// One lane: everything between two passes of Registration.cpp:155-166.
+__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
   if (nc > 0.0) {  // Registration.cpp:82-89
@@ -415,6 +506,34 @@ __global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict_
   st->apply_update = 1;
 }
 
+__global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict__ all_sums, int n_ranks, int has_normals,
+                            double *__restrict__ log, int log_rows) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->done) return;
+  double q[O3D_NSUMS];
+  for (int k = 0; k < O3D_NSUMS; k++) {
+    double v = all_sums[k];
+    for (int r = 1; r < n_ranks; r++) v += all_sums[(size_t)r * O3D_NSUMS + k];
+    q[k] = v;
+  }
+  solve_body(st, q, has_normals, log, log_rows);
+}
+
+// Unsharded loop: partial reduction and estimate in one launch.
+__global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize_solve(const double *__restrict__ partials, int nparts,
+                                                                         IcpState *__restrict__ st, double *__restrict__ sums,
+                                                                         int has_normals, double *__restrict__ log, int log_rows) {
+  if (st->done) return;
+  __shared__ double s[32][O3D_NSUMS];
+  finalize_sums(partials, nparts, s);
+  if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
+  if (threadIdx.x == 0) {
+    double q[O3D_NSUMS];
+    for (int k = 0; k < O3D_NSUMS; k++) q[k] = s[0][k];
+    solve_body(st, q, has_normals, log, log_rows);
+  }
+}
+
 __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__restrict__ corr_sorted, const uint32_t *__restrict__ perm,
                                                              int64_t n, int32_t *__restrict__ out) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK)
@@ -423,7 +542,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__res
 
 }  // namespace
 
-int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out) {
+int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const int g = ctx->pass_grid;
   const bool prof = ctx->prof_on && ctx->prof_n < 512;
   if (prof) {
@@ -443,7 +562,12 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream));
     ctx->prof_n++;
   }
-  hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_BLOCK), 0, ctx->stream, ctx->partials, g, ctx->state, dev_sums_out);
+  if (fuse_solve)
+    hipLaunchKernelGGL(k_icp_finalize_solve, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, g, ctx->state,
+                       dev_sums_out, ctx->has_tgt_normals, ctx->log, ctx->log_rows);
+  else
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, g, ctx->state,
+                       dev_sums_out);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

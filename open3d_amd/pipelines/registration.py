@@ -150,6 +150,11 @@ class IcpSession:
         c = self.ctx
         c.check(c._lib.o3d_icp_pass(c.handle))
 
+    def enqueue_step(self):
+        """pass + estimate for the unsharded loop (one fused finalize+solve launch)."""
+        c = self.ctx
+        c.check(c._lib.o3d_icp_step(c.handle))
+
     def enqueue_pass_to(self, dev_sums_ptr):
         c = self.ctx
         c.check(c._lib.o3d_icp_pass_to(c.handle, C.c_void_p(dev_sums_ptr)))
@@ -221,14 +226,12 @@ class IcpSession:
 
     def run(self, check_every=6):
         """Single-GPU loop: Registration.cpp:154-166."""
-        self.enqueue_pass()
-        self.enqueue_solve()
+        self.enqueue_step()
         it = 0
         while it < self.max_iter:
             upto = min(it + check_every, self.max_iter)
             while it < upto:
-                self.enqueue_pass()
-                self.enqueue_solve()
+                self.enqueue_step()
                 it += 1
             if it < self.max_iter and self.poll()[0]:
                 break

@@ -38,6 +38,9 @@ class HipEngine:
     def solve_from(self, all_sums, n_ranks):
         self.sess.enqueue_solve(all_sums.data_ptr(), n_ranks)
 
+    def step_unsharded(self):
+        self.sess.enqueue_step()
+
     def poll(self):
         return self.sess.poll()
 
@@ -67,6 +70,9 @@ class ShardedICP:
 
     def step(self):
         """One LOOP-A pass + estimate on every rank (enqueue only; no host synchronisation)."""
+        if self.world == 1 and hasattr(self.engine, "step_unsharded"):
+            self.engine.step_unsharded()
+            return
         self.engine.pass_into(self.local)
         if self.world > 1:
             self.dist.all_gather_into_tensor(self.all, self.local, group=self.group)
