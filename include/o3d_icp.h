@@ -134,6 +134,13 @@ O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *o
  * duration in milliseconds over the recorded passes and their number, and clears the record. */
 O3D_API int o3d_icp_profile(o3d_ctx *ctx, int enable);
 O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count);
+/* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 pass instead of the
+ * wave-tile pass; collect_tile_stats != 0 makes the wave-tile pass count {wave-iterations, tiled wave-iterations, staged
+ * candidates, lanes sent to the exact search, box rows, valid lanes} (process-wide counters, read by the second call). */
+O3D_API int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats);
+O3D_API int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset);
+/* Processing order of the source shard after o3d_icp_setup: out[p] = caller's index of the p-th processed point. */
+O3D_API int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out);
 /* Timing breakdown of the last setup (milliseconds, HIP events): [0] grid build, [1] source upload+sort. */
 O3D_API int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]);
 

@@ -38,6 +38,9 @@ _SIGNATURES = {
     "o3d_icp_local_sums": (C.c_void_p, [C.c_void_p]),
     "o3d_icp_step": (C.c_int, [C.c_void_p]),
     "o3d_icp_pass_to": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "o3d_debug_set": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "o3d_debug_tile_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "o3d_debug_get_source_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
     "o3d_icp_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -126,6 +129,20 @@ class Context:
 
     def set_stream(self, stream_handle):
         self.check(self._lib.o3d_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def debug_set(self, force_generic_pass=False, collect_tile_stats=False):
+        self.check(self._lib.o3d_debug_set(self._h, int(force_generic_pass), int(collect_tile_stats)))
+
+    def source_perm(self, n_src):
+        out = np.empty(n_src, np.uint32)
+        self.check(self._lib.o3d_debug_get_source_perm(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def tile_stats(self, reset=True):
+        out = (C.c_uint64 * 8)()
+        self.check(self._lib.o3d_debug_tile_stats(self._h, out, int(reset)))
+        keys = ["wave_iters", "tiled", "candidates", "exact_lanes", "rows", "valid_lanes", "_6", "_7"]
+        return dict(zip(keys, [int(v) for v in out]))
 
     @property
     def handle(self):

@@ -12,6 +12,7 @@
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
+int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
                                int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
 int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
@@ -155,7 +156,7 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   ctx->stream = ctx->own_stream;
   if ((e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   if ((e = hipMalloc((void **)&ctx->state, sizeof(IcpState))) != hipSuccess) return bail(e, "hipMalloc state");
-  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
+  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * (O3D_MAX_GRID + O3D_FIX_GRID))) != hipSuccess) return bail(e, "hipMalloc partials");
   if ((e = hipMalloc((void **)&ctx->sums, sizeof(double) * O3D_NSUMS)) != hipSuccess) return bail(e, "hipMalloc sums");
   *out_ctx = ctx;
   return O3D_OK;
@@ -166,7 +167,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void *bufs[] = {ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
+  void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -287,6 +288,31 @@ int o3d_icp_step(o3d_ctx *ctx) {
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
   return o3d_launch_pass(ctx, ctx->sums, 1);
+}
+
+int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  ctx->force_generic = force_generic_pass;
+  ctx->tile_stats = collect_tile_stats;
+  return O3D_OK;
+}
+
+int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
+  if (!ctx || !host_out) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "no source loaded");
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, hipMemcpyAsync(host_out, ctx->src_perm, sizeof(uint32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
+int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
+  if (!ctx || !out) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  unsigned long long t[8];
+  O3D_TRY(o3d_read_tile_stats(ctx, t, reset));
+  for (int i = 0; i < 8; i++) out[i] = t[i];
+  return O3D_OK;
 }
 
 int o3d_icp_profile(o3d_ctx *ctx, int enable) {

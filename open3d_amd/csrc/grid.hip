@@ -133,8 +133,9 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restr
 
 // K1c: gather the target into cell order (stable: ascending original index inside a cell).
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__restrict__ xyz, const double *__restrict__ nrm,
-                                                              const uint32_t *__restrict__ vals, int64_t n_grid,
-                                                              double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted) {
+                                                              const uint32_t *__restrict__ vals, int64_t n_grid, GridParams gp,
+                                                              double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted,
+                                                              float4 *__restrict__ tgt_local) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const uint32_t i = vals[p];
     double4 q;
@@ -143,6 +144,17 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
     q.z = xyz[3 * (size_t)i + 2];
     q.w = __longlong_as_double((long long)i);
     tgt_sorted[p] = q;
+    {  // fp32 copy relative to the origin of the cell the point was filed under (same arithmetic as k_target_keys)
+      const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+      const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+      const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+      float4 l;
+      l.x = (float)((q.x - gp.gmin[0]) - (double)cx * gp.h);
+      l.y = (float)((q.y - gp.gmin[1]) - (double)cy * gp.h);
+      l.z = (float)((q.z - gp.gmin[2]) - (double)cz * gp.h);
+      l.w = __int_as_float(cx + 1);
+      tgt_local[p] = l;
+    }
     if (nrm) {
       nrm_sorted[3 * p] = nrm[3 * (size_t)i];
       nrm_sorted[3 * p + 1] = nrm[3 * (size_t)i + 1];
@@ -162,12 +174,39 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {
   return x;
 }
 
-// Source ordering key: Morton (Z-order) code of the target-grid cell of the (init-transformed) source point, clamped
-// into the grid.  Only the processing ORDER depends on it -- a workgroup's 256 consecutive points form a compact
-// patch of cells, so its candidate reads hit L1/L2; results are scattered back by original index.
+// 3-D Hilbert index of a cell (Skilling's transpose form, `bits` bits per axis): consecutive indices are face-adjacent
+// cells, so a run of consecutive source points stays inside a small box even where a Z-order curve would jump.
+__device__ __forceinline__ uint64_t hilbert3(uint32_t x0, uint32_t x1, uint32_t x2, int bits) {
+  uint32_t X[3] = {x0, x1, x2};
+  const uint32_t M = 1u << (bits - 1);
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return (spread3(X[0]) << 2) | (spread3(X[1]) << 1) | spread3(X[2]);
+}
+
+// Source ordering key: Hilbert index of the target-grid cell of the (init-transformed) source point, clamped into the
+// grid.  Only the processing ORDER depends on it -- consecutive points form compact patches of cells, which is what
+// the tile pass stages into LDS; results are scattered back by original index.
 __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            const double *__restrict__ T, int apply, uint64_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals) {
+                                                            const double *__restrict__ T, int apply, int bits,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     if (apply) {
@@ -179,7 +218,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restr
     int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    keys[i] = spread3((uint32_t)cx) | (spread3((uint32_t)cy) << 1) | (spread3((uint32_t)cz) << 2);
+    keys[i] = hilbert3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bits);
     vals[i] = (uint32_t)i;
   }
 }
@@ -259,6 +298,8 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     gp.ncell = (uint32_t)((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz);
   }
   ctx->gp = gp;
+  // the fp32 prefilter's error bound assumes fp64 cell origins are exact to well below fp32 resolution
+  ctx->tile_ok = (gp.nx < (1 << 20) && gp.ny < (1 << 20) && gp.nz < (1 << 20)) ? 1 : 0;
 
   // dense table: ncell + 1 prefix entries (+1 sentinel bucket for non-finite points), padded for uint4 access
   const size_t ntab = (size_t)gp.ncell + 2;
@@ -267,6 +308,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   if (n <= 0) return O3D_OK;
 
   O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * (size_t)n));
   if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
 
   const size_t ntiles = o3d_sort_num_tiles(n);
@@ -288,7 +330,8 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   ctx->n_tgt_grid = nfinite;
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
-                       (const uint32_t *)vals, nfinite, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr);
+                       (const uint32_t *)vals, nfinite, gp, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr,
+                       ctx->tgt_local);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }
@@ -322,11 +365,12 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   for (int i = 0; i < 16; i++) hT[i] = init_colmajor[i];
   O3D_HIP(ctx, hipMemcpyAsync(dT, hT, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream));
   const int g = grid_for(n);
+  int axis_bits = ceil_log2((uint64_t)std::max(std::max(ctx->gp.nx, ctx->gp.ny), ctx->gp.nz));
+  axis_bits = std::min(std::max(axis_bits, 1), 21);
   hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, (const double *)dT,
-                     apply_init, (uint64_t *)keys, ctx->src_perm);
-  const int axis_bits = ceil_log2((uint64_t)std::max(std::max(ctx->gp.nx, ctx->gp.ny), ctx->gp.nz));
+                     apply_init, axis_bits, (uint64_t *)keys, ctx->src_perm);
   O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, ctx->src_perm, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
-                             std::min(63, 3 * (axis_bits < 1 ? 1 : axis_bits))));
+                             3 * axis_bits));
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
                      ctx->src_sorted);
   O3D_HIP(ctx, hipGetLastError());

@@ -145,84 +145,45 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
   }
 }
 
+// Per-lane running sums of the next estimate for one accepted correspondence.
 template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src, int64_t n_src, const double4 *__restrict__ tgt,
-                                                         const double *__restrict__ nrm, const uint32_t *__restrict__ cell_start,
-                                                         GridParams gp, double thr, const IcpState *__restrict__ st,
-                                                         int32_t *__restrict__ corr, double *__restrict__ partials) {
-  if (st->done) return;
-  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
-  const int apply = st->apply_update;
-  double T[12];  // element (r, c) of the pending update at T[c * 3 + r]
+__device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y, double z, const Best &b,
+                                           const double *__restrict__ nrm, double cx0, double cy0, double cz0) {
+  if (EST == O3D_EST_POINT_TO_PLANE) {
+    const double n0 = nrm[3 * (size_t)b.pos], n1 = nrm[3 * (size_t)b.pos + 1], n2 = nrm[3 * (size_t)b.pos + 2];
+    double r = (x - b.x) * n0;
+    r = r + (y - b.y) * n1;
+    r = r + (z - b.z) * n2;
+    double J[6];
+    J[0] = y * n2 - z * n1;
+    J[1] = z * n0 - x * n2;
+    J[2] = x * n1 - y * n0;
+    J[3] = n0; J[4] = n1; J[5] = n2;
+    int k = 0;
 #pragma unroll
-  for (int c = 0; c < 4; c++)
+    for (int a = 0; a < 6; a++)
 #pragma unroll
-    for (int r = 0; r < 3; r++) T[c * 3 + r] = st->update[c * 4 + r];
-  const double w0 = st->update[3], w1 = st->update[7], w2 = st->update[11], w3 = st->update[15];
-  const double cx0 = st->centre[0], cy0 = st->centre[1], cz0 = st->centre[2];
-
-  double acc[30];
+      for (int c = a; c < 6; c++) acc[k++] += J[a] * J[c];
 #pragma unroll
-  for (int k = 0; k < 30; k++) acc[k] = 0.0;
-
-  // contiguous chunk of the (cell-ordered) source per workgroup
-  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the Morton
-  // order so that neighbouring patches meet in the same L2.  The launch grid is a multiple of 8.
-  const int64_t per = ((n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
-  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int64_t beg = (int64_t)chunk * per;
-  const int64_t end = beg + per < n_src ? beg + per : n_src;
-
-  for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
-    double x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
-    if (apply) {
-      // Eigen 4x4 * [p;1], then divide by w (Geometry3D.cpp:79-80)
-      double nx_ = ((T[0] * x + T[3] * y) + T[6] * z) + T[9];
-      double ny_ = ((T[1] * x + T[4] * y) + T[7] * z) + T[10];
-      double nz_ = ((T[2] * x + T[5] * y) + T[8] * z) + T[11];
-      double nw_ = ((w0 * x + w1 * y) + w2 * z) + w3;
-      x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
-      src[3 * i] = x; src[3 * i + 1] = y; src[3 * i + 2] = z;
-    }
-    Best b;
-    b.d2 = thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
-    nn_search(tgt, cell_start, gp, x, y, z, b);
-    corr[i] = (int32_t)b.idx;
-    if (b.idx >= 0) {
-      if (EST == O3D_EST_POINT_TO_PLANE) {
-        const double n0 = nrm[3 * (size_t)b.pos], n1 = nrm[3 * (size_t)b.pos + 1], n2 = nrm[3 * (size_t)b.pos + 2];
-        double r = (x - b.x) * n0;
-        r = r + (y - b.y) * n1;
-        r = r + (z - b.z) * n2;
-        double J[6];
-        J[0] = y * n2 - z * n1;
-        J[1] = z * n0 - x * n2;
-        J[2] = x * n1 - y * n0;
-        J[3] = n0; J[4] = n1; J[5] = n2;
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int c = a; c < 6; c++) acc[k++] += J[a] * J[c];
-#pragma unroll
-        for (int a = 0; a < 6; a++) acc[21 + a] += J[a] * r;
-        acc[27] += r * r;
-      } else {
-        const double sx = x - cx0, sy = y - cy0, sz = z - cz0;
-        const double tx = b.x - cx0, ty = b.y - cy0, tz = b.z - cz0;
-        acc[0] += sx; acc[1] += sy; acc[2] += sz;
-        acc[3] += tx; acc[4] += ty; acc[5] += tz;
-        acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
-        acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
-        acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
-        acc[15] += (sx * sx + sy * sy) + sz * sz;
-      }
-      acc[O3D_SUM_D2] += b.d2;
-      acc[O3D_SUM_NC] += 1.0;
-    }
+    for (int a = 0; a < 6; a++) acc[21 + a] += J[a] * r;
+    acc[27] += r * r;
+  } else {
+    const double sx = x - cx0, sy = y - cy0, sz = z - cz0;
+    const double tx = b.x - cx0, ty = b.y - cy0, tz = b.z - cz0;
+    acc[0] += sx; acc[1] += sy; acc[2] += sz;
+    acc[3] += tx; acc[4] += ty; acc[5] += tz;
+    acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
+    acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
+    acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
+    acc[15] += (sx * sx + sy * sy) + sz * sz;
   }
+  acc[O3D_SUM_D2] += b.d2;
+  acc[O3D_SUM_NC] += 1.0;
+}
 
-  // wavefront shuffle reduction, then a fixed-order LDS combine across the four waves
+// Wavefront shuffle reduction, then a fixed-order LDS combine across the four waves -> one partial row per chunk.
+__device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*red)[O3D_NSUMS], double *__restrict__ partials,
+                                                   unsigned chunk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 30; k++) {
@@ -235,6 +196,390 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(double *__restrict__ src
     if (threadIdx.x < 30) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     partials[(size_t)chunk * O3D_NSUMS + threadIdx.x] = v;
   }
+}
+
+// Optional counters of the wave-tile pass (tests and tuning): [0] wave-iterations, [1] tiled wave-iterations,
+// [2] staged candidates, [3] lanes that ran the exact per-lane search, [4] rows visited, [5] valid lanes.
+__device__ unsigned long long g_tile_stats[8];
+
+struct PassArgs {
+  int stats;
+  double *src;
+  int64_t n_src;
+  const double4 *tgt;
+  const float4 *tgt_local;
+  const double *nrm;
+  const uint32_t *cell_start;
+  const IcpState *st;
+  int32_t *corr;
+  double *partials;
+  double thr;
+};
+
+__device__ __forceinline__ void load_update(const IcpState *st, double (&T)[12], double (&w)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) T[c * 3 + r] = st->update[c * 4 + r];  // element (r, c) at T[c * 3 + r]
+    w[c] = st->update[c * 4 + 3];
+  }
+}
+
+// Eigen 4x4 * [p;1], then divide by w (Geometry3D.cpp:79-80)
+__device__ __forceinline__ void apply_update(const double (&T)[12], const double (&w)[4], double &x, double &y, double &z) {
+  const double nx_ = ((T[0] * x + T[3] * y) + T[6] * z) + T[9];
+  const double ny_ = ((T[1] * x + T[4] * y) + T[7] * z) + T[10];
+  const double nz_ = ((T[2] * x + T[5] * y) + T[8] * z) + T[11];
+  const double nw_ = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
+  x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
+}
+
+// Generic pass: every lane searches its own 3x3x3 cell block in fp64 (any grid, any source distribution).
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(PassArgs a, GridParams gp) {
+  if (a.st->done) return;
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  const int apply = a.st->apply_update;
+  double T[12], w[4];
+  load_update(a.st, T, w);
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+
+  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the Morton
+  // order so that neighbouring patches meet in the same L2.  The launch grid is a multiple of 8.
+  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t beg = (int64_t)chunk * per;
+  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+
+  for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
+    double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
+    if (apply) {
+      apply_update(T, w, x, y, z);
+      a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
+    }
+    Best b;
+    b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+    nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
+    a.corr[i] = (int32_t)b.idx;
+    if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+  }
+  block_reduce_store(acc, red, a.partials, chunk);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile pass (the fast path).  Every 16-lane quarter of a wavefront (a "group") takes 16 consecutive source points of
+// the Morton order -- a compact patch of ~2x2 cells -- and
+//   1. finds the patch's bounding box of cells (group min/max by DPP shuffles), widened by one cell on every side;
+//   2. stages every target point of that box ONCE into the group's LDS slice as fp32 coordinates relative to the box
+//      origin (w = position in tgt_sorted).  The box is a set of x-runs, one per (y, z) row; their lengths are
+//      prefix-summed in the group, and each lane fetches up to 8 staged items whose row it finds by a 6-step binary
+//      search of the prefix in LDS -- so all candidate loads of the tile are in flight together;
+//   3. lets each lane test every staged candidate of its group in a wave-uniform loop (ds_read_b128 serves one
+//      address per 16-lane group per cycle: the four groups' broadcasts cost nothing extra), tracking the best and
+//      second-best fp32 distance: 11 full-rate VALU instructions per candidate, no divergence, no per-lane gathers;
+//   4. confirms the winner in fp64 from tgt_sorted (arithmetic identical to the generic path).  A lane whose fp32
+//      result is not decisive -- runner-up within the fp32 error bound, winner within the bound of the acceptance
+//      threshold, query outside the grid, box too large -- runs the exact per-lane fp64 search, so the result is always
+//      the exact argmin over (d2, index).
+// fp32 error budget (h = cell size, box <= 12 cells per axis): every staged coordinate and query coordinate is within
+// 2e-6 h of its exact box-relative value, so |d2_fp32 - d2| <= 1.2e-5 h^2 for any candidate that can matter
+// (d2 <= ~h^2).  kTileErr = 3e-5 (x h^2) is the bound e: decisive means second - best > 2e and |best - thr| > e.
+constexpr int kG = 8;                   // lanes per group
+constexpr int kNG = O3D_WAVE / kG;      // groups per wave
+constexpr int kGroupCap = 96;           // staged candidates per group (x 16 B of LDS)
+constexpr int kRowsPerLane = 4;
+constexpr int kGroupRows = kG * kRowsPerLane;  // (y, z) rows of the widened box
+constexpr int kItemsPerLane = kGroupCap / kG;  // staged items fetched by one lane
+constexpr int kSlice = kGroupCap + 1;   // float4 stride between group slices: rotates each group by 4 LDS banks
+constexpr int kTileMaxX = 10;           // cells per axis of the widened box
+constexpr float kTileErr = 3e-5f;
+
+struct WaveLds {
+  float4 cand[kNG * kSlice];
+  uint32_t roff[kNG][kGroupRows];
+  uint32_t rs[kNG][kGroupRows];
+};
+
+__device__ __forceinline__ int grp_min_i(int v) {
+#pragma unroll
+  for (int d = kG / 2; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, O3D_WAVE));
+  return v;
+}
+__device__ __forceinline__ int grp_max_i(int v) {
+#pragma unroll
+  for (int d = kG / 2; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, O3D_WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, O3D_WAVE));
+  return v;
+}
+
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridParams gp) {
+  if (a.st->done) return;
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  __shared__ WaveLds lds[O3D_BLOCK / O3D_WAVE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / kG, lg = lane % kG;
+  float4 *my = lds[wave].cand + grp * kSlice;
+  uint32_t *my_roff = lds[wave].roff[grp];
+  uint32_t *my_rs = lds[wave].rs[grp];
+  const int apply = a.st->apply_update;
+  double T[12], w[4];
+  load_update(a.st, T, w);
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+
+  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t beg = (int64_t)chunk * per;
+  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+  const float hf = (float)gp.h;
+  const float err = kTileErr * hf * hf;
+  const float thrf = (float)a.thr;
+
+  for (int64_t base = beg + wave * O3D_WAVE; base < end; base += O3D_BLOCK) {  // wave-uniform trip count
+    const int64_t i = base + lane;
+    const bool valid = i < end;
+    double x = 0, y = 0, z = 0;
+    if (valid) {
+      x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
+      if (apply) {
+        apply_update(T, w, x, y, z);
+        a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
+      }
+    }
+    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
+    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
+    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
+    const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
+    bool exact = valid && !inside;  // lanes that need the per-lane fp64 search
+    Best b;
+    b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+
+    // 1. widened bounding box of the group's inside lanes (uniform within the group)
+    const int big = 1 << 30;
+    const int x0 = grp_min_i(inside ? cx : big), x1 = grp_max_i(inside ? cx : -big);
+    const int y0 = grp_min_i(inside ? cy : big), y1 = grp_max_i(inside ? cy : -big);
+    const int z0 = grp_min_i(inside ? cz : big), z1 = grp_max_i(inside ? cz : -big);
+    bool tile = x1 >= x0;  // at least one inside lane
+    // padded x cell indices of every row's run [px0, px1] = unpadded x0-1 .. x1+1 (the pads at -1 and nx are empty cells)
+    const int px0 = x0, px1 = x1 + 2;
+    const int by0 = max(y0 - 1, 0), by1 = min(y1 + 1, gp.ny - 1);
+    const int bz0 = max(z0 - 1, 0), bz1 = min(z1 + 1, gp.nz - 1);
+    const int nby = by1 - by0 + 1, nbz = bz1 - bz0 + 1;
+    const int nrows = nby * nbz;
+    tile = tile && (px1 - px0 + 1) <= kTileMaxX && nby <= kTileMaxX && nbz <= kTileMaxX && nrows <= kGroupRows;
+    const uint32_t magic = tile ? (65536u / (uint32_t)nby + 1u) : 0u;  // floor(r / nby) = (r * magic) >> 16 for r < 64
+
+    // 2a. lane owns rows 4*lg .. 4*lg+3: run starts and lengths from the dense cell table, prefix over the group
+    uint32_t rs4[kRowsPerLane], rl4[kRowsPerLane];
+#pragma unroll
+    for (int q = 0; q < kRowsPerLane; q++) {
+      rs4[q] = 0; rl4[q] = 0;
+      const int r = kRowsPerLane * lg + q;
+      if (tile && r < nrows) {
+        const int zq = (int)(((uint32_t)r * magic) >> 16);
+        const int yy = by0 + (r - zq * nby), zz = bz0 + zq;
+        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+        rs4[q] = a.cell_start[row + (uint32_t)px0];
+        rl4[q] = a.cell_start[row + (uint32_t)px1 + 1u] - rs4[q];
+      }
+    }
+    const uint32_t lane_tot = rl4[0] + rl4[1] + rl4[2] + rl4[3];
+    uint32_t inc = lane_tot;
+#pragma unroll
+    for (int d = 1; d < kG; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, kG);
+      if (lg >= d) inc += o;
+    }
+    const int tot = (int)__shfl(inc, kG - 1, kG);
+    tile = tile && tot <= kGroupCap;
+    {
+      const uint32_t never = 0x7fffffffu;  // rows past the box (or an untiled group): never selected by the search
+      uint32_t o = inc - lane_tot;
+      uint4 ro;
+      ro.x = (tile && kRowsPerLane * lg + 0 < nrows) ? o : never; o += rl4[0];
+      ro.y = (tile && kRowsPerLane * lg + 1 < nrows) ? o : never; o += rl4[1];
+      ro.z = (tile && kRowsPerLane * lg + 2 < nrows) ? o : never; o += rl4[2];
+      ro.w = (tile && kRowsPerLane * lg + 3 < nrows) ? o : never;
+      *reinterpret_cast<uint4 *>(my_roff + kRowsPerLane * lg) = ro;
+      *reinterpret_cast<uint4 *>(my_rs + kRowsPerLane * lg) = make_uint4(rs4[0], rs4[1], rs4[2], rs4[3]);
+    }
+    const int gtot = tile ? tot : 0;
+    const int max_tot = (wave_max_i(gtot) + 3) & ~3;  // wave-uniform scan length, multiple of the unroll factor
+    __builtin_amdgcn_wave_barrier();
+
+    // 2b. stage: item t of the group -> (row, k) by binary search of the row prefix in LDS; the candidate loads of
+    //     half a tile are in flight together
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      constexpr int kH = kItemsPerLane / 2;
+      float4 it[kH];
+      uint32_t itpos[kH];
+#pragma unroll
+      for (int m = 0; m < kH; m++) {
+        const int t = lg + kG * (half * kH + m);
+        uint32_t rho = 0;
+#pragma unroll
+        for (int step = kGroupRows / 2; step >= 1; step >>= 1)
+          if (my_roff[rho + step] <= (uint32_t)t) rho += step;
+        itpos[m] = my_rs[rho] + ((uint32_t)t - my_roff[rho]);
+        const int zq = (int)((rho * magic) >> 16);
+        it[m].y = (float)((int)rho - zq * nby) * hf;  // row offsets inside the box
+        it[m].z = (float)zq * hf;
+        it[m].x = 0.f; it[m].w = 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < kH; m++) {
+        const int t = lg + kG * (half * kH + m);
+        if (t < gtot) {
+          const float4 c = a.tgt_local[itpos[m]];
+          it[m].x = c.x + (float)(__float_as_int(c.w) - px0) * hf;
+          it[m].y += c.y;
+          it[m].z += c.z;
+          it[m].w = __uint_as_float(itpos[m]);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kH; m++) {
+        const int t = lg + kG * (half * kH + m);
+        if (t < gtot) my[t] = it[m];
+        else if (t < max_tot) my[t] = make_float4(1e18f, 1e18f, 1e18f, 0.f);  // padding: never best nor runner-up
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // 3. wave-uniform scan of the staged candidates (each group reads its own slice)
+    const float qx = (float)((x - gp.gmin[0]) - (double)(px0 - 1) * gp.h);
+    const float qy = (float)((y - gp.gmin[1]) - (double)by0 * gp.h);
+    const float qz = (float)((z - gp.gmin[2]) - (double)bz0 * gp.h);
+    float best = INFINITY, second = INFINITY;
+    uint32_t bpos = 0;
+    for (int j = 0; j < max_tot; j += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float4 c = my[j + u];
+        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        second = fminf(second, fmaxf(d2, best));
+        bpos = d2 < best ? __float_as_uint(c.w) : bpos;
+        best = fminf(best, d2);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // 4. decisive?  then confirm the winner in fp64; otherwise leave the point to the exact search
+    if (inside) {
+      if (!tile) {
+        exact = true;
+      } else {
+        const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
+        const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
+        if (best <= thrf + err && (near_tie || near_thr)) {
+          exact = true;
+        } else if (best < thrf) {
+          const double4 p = a.tgt[bpos];
+          const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+          double d2 = ddx * ddx;
+          d2 = d2 + ddy * ddy;
+          d2 = d2 + ddz * ddz;
+          if (d2 < a.thr) {
+            b.d2 = d2; b.idx = __double_as_longlong(p.w); b.pos = bpos;
+            b.x = p.x; b.y = p.y; b.z = p.z;
+          } else {
+            exact = true;  // cannot happen within the error bound; stay exact regardless
+          }
+        }
+      }
+    }
+    if (a.stats) {
+      const unsigned long long ne = __popcll(__ballot(exact)), nv = __popcll(__ballot(valid));
+      const unsigned long long nt = __popcll(__ballot(tile && lg == 0));
+      unsigned long long csum = (lg == 0) ? (unsigned long long)gtot : 0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) csum += __shfl_xor(csum, d, O3D_WAVE);
+      if (lane == 0) {
+        atomicAdd(&g_tile_stats[0], (unsigned long long)kNG);
+        atomicAdd(&g_tile_stats[1], nt);
+        atomicAdd(&g_tile_stats[2], csum);
+        atomicAdd(&g_tile_stats[3], ne);
+        atomicAdd(&g_tile_stats[4], (unsigned long long)max_tot);
+        atomicAdd(&g_tile_stats[5], nv);
+      }
+    }
+    if (valid) {
+      // undecided lanes are left to k_icp_fixup (corr = -2): keeps the exact search's registers out of this kernel
+      a.corr[i] = exact ? -2 : (int32_t)b.idx;
+      if (!exact && b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+    }
+  }
+  block_reduce_store(acc, red, a.partials, chunk);
+}
+
+// Exact per-lane fp64 search for the points the tile pass left undecided (corr == -2).  Each workgroup walks a
+// contiguous slice of the source in 4096-point tiles, compacts the pending indices of a tile into LDS in index order
+// (block prefix scan: deterministic), and processes the compact list densely.  Its sums go to partial rows of their
+// own behind the tile pass's rows.
+constexpr int kFixTile = 4096;
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams gp, int row0) {
+  if (a.st->done) return;
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  __shared__ uint32_t list[kFixTile];
+  __shared__ uint32_t wtot[O3D_BLOCK / O3D_WAVE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + kFixTile - 1) / kFixTile * kFixTile;
+  const int64_t beg = (int64_t)blockIdx.x * per;
+  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+  for (int64_t t0 = beg; t0 < end; t0 += kFixTile) {
+    // thread owns 16 consecutive entries (four int4 loads would need alignment: t0 and 16*tid are multiples of 16)
+    const int64_t e0 = t0 + 16 * (int64_t)threadIdx.x;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      if (e0 + k < end && a.corr[e0 + k] == -2) mask |= 1u << k;
+    const uint32_t cnt = __popc(mask);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < O3D_WAVE; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, O3D_WAVE);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < O3D_BLOCK / O3D_WAVE; q++) {
+      if (q < wave) wbase += wtot[q];
+      total += wtot[q];
+    }
+    uint32_t o = wbase + inc - cnt;
+    for (uint32_t m = mask; m; m &= m - 1) list[o++] = (uint32_t)(e0 - t0) + (uint32_t)(__ffs(m) - 1);
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < total; q += O3D_BLOCK) {
+      const int64_t i = t0 + list[q];
+      const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
+      Best b;
+      b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+      nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
+      a.corr[i] = (int32_t)b.idx;
+      if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+    }
+    __syncthreads();
+  }
+  block_reduce_store(acc, red, a.partials, (unsigned)(row0 + blockIdx.x));
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -550,23 +895,36 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
       if (!ctx->prof_ev[2 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[2 * ctx->prof_n + k]));
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream));
   }
-  if (ctx->estimation == O3D_EST_POINT_TO_PLANE)
-    hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
-                       ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
-                       ctx->partials);
-  else
-    hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_sorted, ctx->n_src,
-                       ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->gp, ctx->thr, ctx->state, ctx->corr_sorted,
-                       ctx->partials);
+  PassArgs pa;
+  pa.stats = ctx->tile_stats;
+  pa.src = ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
+  pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
+  pa.partials = ctx->partials; pa.thr = ctx->thr;
+  const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
+  int nparts = g;
+  if (ctx->tile_ok && !ctx->force_generic) {
+    const int gf = O3D_FIX_GRID;
+    nparts = g + gf;
+    if (p2l) {
+      hipLaunchKernelGGL(k_icp_pass_tile<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+      hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
+    } else {
+      hipLaunchKernelGGL(k_icp_pass_tile<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+      hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
+    }
+  } else {
+    if (p2l) hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  }
   if (prof) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream));
     ctx->prof_n++;
   }
   if (fuse_solve)
-    hipLaunchKernelGGL(k_icp_finalize_solve, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, g, ctx->state,
+    hipLaunchKernelGGL(k_icp_finalize_solve, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, nparts, ctx->state,
                        dev_sums_out, ctx->has_tgt_normals, ctx->log, ctx->log_rows);
   else
-    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, g, ctx->state,
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, nparts, ctx->state,
                        dev_sums_out);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
@@ -586,5 +944,15 @@ int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out) {
   hipLaunchKernelGGL(k_scatter_corr, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->corr_sorted, ctx->src_perm, ctx->n_src,
                      dev_out);
   O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset) {
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  O3D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    O3D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), z, sizeof z));
+  }
   return O3D_OK;
 }

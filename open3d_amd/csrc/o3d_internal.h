@@ -13,6 +13,7 @@
 #define O3D_NUM_CU 256
 #define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
 #define O3D_NSUMS 32
+#define O3D_FIX_GRID 512  // workgroups of k_icp_fixup (partial rows behind the pass rows)
 
 // ---- sums layout (per pass, fp64) -------------------------------------------
 // point-to-plane: [0..20] JTJ upper triangle row-major, [21..26] JTr, [27] sum r^2
@@ -64,6 +65,11 @@ struct o3d_ctx {
   int64_t n_tgt_grid = 0;   // finite points placed in the grid
   double4 *tgt_sorted = nullptr;  // {x, y, z, bits(original index)} in cell order
   double *nrm_sorted = nullptr;   // 3 doubles per sorted target point (nullable)
+  float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
+  size_t cap_local = 0;
+  int tile_ok = 0;                // fp32 wave-tile prefilter usable on this grid
+  int tile_stats = 0;             // collect g_tile_stats
+  int force_generic = 0;          // tests: run the generic per-lane fp64 pass instead of the wave-tile pass
   uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
   size_t cap_tgt = 0, cap_nrm = 0, cap_cells = 0;
 
