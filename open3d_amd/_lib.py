@@ -130,8 +130,9 @@ class Context:
     def set_stream(self, stream_handle):
         self.check(self._lib.o3d_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
 
-    def debug_set(self, force_generic_pass=False, collect_tile_stats=False):
-        self.check(self._lib.o3d_debug_set(self._h, int(force_generic_pass), int(collect_tile_stats)))
+    def debug_set(self, use_tile_search=False, collect_tile_stats=False):
+        """use_tile_search: run the LDS-tile fp32-prefilter search kernel instead of the per-lane fp64 search."""
+        self.check(self._lib.o3d_debug_set(self._h, 2 if use_tile_search else 0, int(collect_tile_stats)))
 
     def source_perm(self, n_src):
         out = np.empty(n_src, np.uint32)

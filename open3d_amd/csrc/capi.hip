@@ -168,7 +168,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
+                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -292,7 +292,8 @@ int o3d_icp_step(o3d_ctx *ctx) {
 
 int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
-  ctx->force_generic = force_generic_pass;
+  ctx->force_generic = force_generic_pass & 1;
+  ctx->use_tile = (force_generic_pass & 2) ? 1 : 0;
   ctx->tile_stats = collect_tile_stats;
   return O3D_OK;
 }

@@ -30,7 +30,6 @@ struct Best {
   double d2;
   long long idx;
   uint32_t pos;
-  double x, y, z;
 };
 
 __device__ __forceinline__ void consider(const double4 &p, uint32_t j, double x, double y, double z, Best &b) {
@@ -41,7 +40,6 @@ __device__ __forceinline__ void consider(const double4 &p, uint32_t j, double x,
   const long long id = __double_as_longlong(p.w);
   if (d2 < b.d2 || (d2 == b.d2 && id < b.idx)) {
     b.d2 = d2; b.idx = id; b.pos = j;
-    b.x = p.x; b.y = p.y; b.z = p.z;
   }
 }
 
@@ -148,12 +146,13 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
 // Per-lane running sums of the next estimate for one accepted correspondence.
 template <int EST>
 __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y, double z, const Best &b,
-                                           const double *__restrict__ nrm, double cx0, double cy0, double cz0) {
+                                           const double4 &p, const double *__restrict__ nrm, double cx0, double cy0,
+                                           double cz0) {
   if (EST == O3D_EST_POINT_TO_PLANE) {
     const double n0 = nrm[3 * (size_t)b.pos], n1 = nrm[3 * (size_t)b.pos + 1], n2 = nrm[3 * (size_t)b.pos + 2];
-    double r = (x - b.x) * n0;
-    r = r + (y - b.y) * n1;
-    r = r + (z - b.z) * n2;
+    double r = (x - p.x) * n0;
+    r = r + (y - p.y) * n1;
+    r = r + (z - p.z) * n2;
     double J[6];
     J[0] = y * n2 - z * n1;
     J[1] = z * n0 - x * n2;
@@ -169,7 +168,7 @@ __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y
     acc[27] += r * r;
   } else {
     const double sx = x - cx0, sy = y - cy0, sz = z - cz0;
-    const double tx = b.x - cx0, ty = b.y - cy0, tz = b.z - cz0;
+    const double tx = p.x - cx0, ty = p.y - cy0, tz = p.z - cz0;
     acc[0] += sx; acc[1] += sy; acc[2] += sz;
     acc[3] += tx; acc[4] += ty; acc[5] += tz;
     acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
@@ -211,10 +210,14 @@ struct PassArgs {
   const double *nrm;
   const uint32_t *cell_start;
   const IcpState *st;
-  int32_t *corr;
+  int32_t *corr;   // per processing position: target index, -1 none, -2 left to k_icp_fixup, -3 unconfirmed candidate at pos
+  uint32_t *pos;   // per processing position: position of the match in tgt_sorted
   double *partials;
   double thr;
 };
+#define O3D_CORR_NONE (-1)
+#define O3D_CORR_PENDING (-2)
+#define O3D_CORR_CANDIDATE (-3)
 
 __device__ __forceinline__ void load_update(const IcpState *st, double (&T)[12], double (&w)[4]) {
 #pragma unroll
@@ -234,26 +237,19 @@ __device__ __forceinline__ void apply_update(const double (&T)[12], const double
   x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
 }
 
-// Generic pass: every lane searches its own 3x3x3 cell block in fp64 (any grid, any source distribution).
-template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(PassArgs a, GridParams gp) {
+// Generic search pass: every lane searches its own 3x3x3 cell block in fp64 (any grid, any source distribution).
+// Applies the pending update in place, writes the correspondence and its position in tgt_sorted.
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams gp) {
   if (a.st->done) return;
-  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
   const int apply = a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
-  double acc[30];
-#pragma unroll
-  for (int k = 0; k < 30; k++) acc[k] = 0.0;
-
-  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the Morton
+  // Workgroups b and b + 8 share an XCD (round-robin dispatch): give each XCD one contiguous eighth of the curve
   // order so that neighbouring patches meet in the same L2.  The launch grid is a multiple of 8.
   const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
   const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t beg = (int64_t)chunk * per;
   const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-
   for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
     double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
     if (apply) {
@@ -261,10 +257,52 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass(PassArgs a, GridParams g
       a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
     }
     Best b;
-    b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+    b.d2 = a.thr; b.idx = -1; b.pos = 0;
     nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
     a.corr[i] = (int32_t)b.idx;
-    if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+    a.pos[i] = b.pos;
+  }
+}
+
+// Accumulation pass: streams the source with its correspondences, gathers the matched target point (and normal) by
+// position, and reduces the sums of the next estimate -- utility::ComputeJTJandJTr (utility/Eigen.cpp:159-201) with the
+// point-to-plane rows of TransformationEstimation.cpp:79-86, or the Umeyama moments of :53-59 -- per lane in fp64, then
+// by wavefront shuffles and an LDS tree to one 32-double partial row per chunk.  A candidate proposed by the tile pass
+// (corr == -3) is confirmed here in fp64 with the arithmetic of the exact search; if it fails it is left to k_icp_fixup.
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
+  if (a.st->done) return;
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t beg = (int64_t)chunk * per;
+  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+  for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
+    const int32_t c = a.corr[i];
+    if (c >= 0 || c == O3D_CORR_CANDIDATE) {
+      const uint32_t pos = a.pos[i];
+      const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
+      const double4 p = a.tgt[pos];
+      Best b;
+      const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+      double d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      b.d2 = d2; b.idx = __double_as_longlong(p.w); b.pos = pos;
+      if (c == O3D_CORR_CANDIDATE) {
+        if (d2 < a.thr) {
+          a.corr[i] = (int32_t)b.idx;
+        } else {
+          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the tile pass's error bound; stay exact regardless
+          continue;
+        }
+      }
+      accumulate<EST>(acc, x, y, z, b, p, a.nrm, cx0, cy0, cz0);
+    }
   }
   block_reduce_store(acc, red, a.partials, chunk);
 }
@@ -319,10 +357,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridParams gp) {
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_tile(PassArgs a, GridParams gp) {
   if (a.st->done) return;
-  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
   __shared__ WaveLds lds[O3D_BLOCK / O3D_WAVE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / kG, lg = lane % kG;
@@ -332,10 +368,6 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridPar
   const int apply = a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
-  double acc[30];
-#pragma unroll
-  for (int k = 0; k < 30; k++) acc[k] = 0.0;
 
   const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
   const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -361,8 +393,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridPar
     const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
     const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
     bool exact = valid && !inside;  // lanes that need the per-lane fp64 search
-    Best b;
-    b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+    int32_t verdict = O3D_CORR_NONE;
 
     // 1. widened bounding box of the group's inside lanes (uniform within the group)
     const int big = 1 << 30;
@@ -476,28 +507,15 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridPar
     }
     __builtin_amdgcn_wave_barrier();
 
-    // 4. decisive?  then confirm the winner in fp64; otherwise leave the point to the exact search
+    // 4. decisive?  then the winner goes to k_icp_accumulate for fp64 confirmation; otherwise to the exact search
     if (inside) {
       if (!tile) {
         exact = true;
       } else {
         const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
         const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
-        if (best <= thrf + err && (near_tie || near_thr)) {
-          exact = true;
-        } else if (best < thrf) {
-          const double4 p = a.tgt[bpos];
-          const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
-          double d2 = ddx * ddx;
-          d2 = d2 + ddy * ddy;
-          d2 = d2 + ddz * ddz;
-          if (d2 < a.thr) {
-            b.d2 = d2; b.idx = __double_as_longlong(p.w); b.pos = bpos;
-            b.x = p.x; b.y = p.y; b.z = p.z;
-          } else {
-            exact = true;  // cannot happen within the error bound; stay exact regardless
-          }
-        }
+        if (best <= thrf + err && (near_tie || near_thr)) exact = true;
+        else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
       }
     }
     if (a.stats) {
@@ -516,12 +534,10 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_pass_tile(PassArgs a, GridPar
       }
     }
     if (valid) {
-      // undecided lanes are left to k_icp_fixup (corr = -2): keeps the exact search's registers out of this kernel
-      a.corr[i] = exact ? -2 : (int32_t)b.idx;
-      if (!exact && b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+      a.corr[i] = exact ? O3D_CORR_PENDING : verdict;
+      a.pos[i] = bpos;
     }
   }
-  block_reduce_store(acc, red, a.partials, chunk);
 }
 
 // Exact per-lane fp64 search for the points the tile pass left undecided (corr == -2).  Each workgroup walks a
@@ -572,10 +588,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams 
       const int64_t i = t0 + list[q];
       const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
       Best b;
-      b.d2 = a.thr; b.idx = -1; b.pos = 0; b.x = 0; b.y = 0; b.z = 0;
+      b.d2 = a.thr; b.idx = -1; b.pos = 0;
       nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
       a.corr[i] = (int32_t)b.idx;
-      if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.nrm, cx0, cy0, cz0);
+      a.pos[i] = b.pos;
+      if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], a.nrm, cx0, cy0, cz0);
     }
     __syncthreads();
   }
@@ -587,9 +604,16 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams 
 #define O3D_FIN_THREADS 1024
 __device__ __forceinline__ void finalize_sums(const double *__restrict__ partials, int nparts, double (*s)[O3D_NSUMS]) {
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-  double v = 0.0;
-  for (int b = g; b < nparts; b += 32) v += partials[(size_t)b * O3D_NSUMS + k];
-  s[g][k] = v;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four independent chains: the row loads overlap
+  int b = g;
+  for (; b + 96 < nparts; b += 128) {
+    v0 += partials[(size_t)b * O3D_NSUMS + k];
+    v1 += partials[(size_t)(b + 32) * O3D_NSUMS + k];
+    v2 += partials[(size_t)(b + 64) * O3D_NSUMS + k];
+    v3 += partials[(size_t)(b + 96) * O3D_NSUMS + k];
+  }
+  for (; b < nparts; b += 32) v0 += partials[(size_t)b * O3D_NSUMS + k];
+  s[g][k] = (v0 + v1) + (v2 + v3);
   __syncthreads();
   if (threadIdx.x < O3D_NSUMS) {
     double t = s[0][k];
@@ -901,20 +925,19 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
-  int nparts = g;
-  if (ctx->tile_ok && !ctx->force_generic) {
-    const int gf = O3D_FIX_GRID;
-    nparts = g + gf;
-    if (p2l) {
-      hipLaunchKernelGGL(k_icp_pass_tile<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-      hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
-    } else {
-      hipLaunchKernelGGL(k_icp_pass_tile<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-      hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
-    }
+  pa.pos = ctx->pos_sorted;
+  const int gf = O3D_FIX_GRID;
+  const int nparts = g + gf;
+  const bool tiled = ctx->tile_ok && ctx->use_tile && !ctx->force_generic;
+  if (tiled) hipLaunchKernelGGL(k_icp_search_tile, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  else hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+  else hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+  if (tiled) {
+    if (p2l) hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
+    else hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
   } else {
-    if (p2l) hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else hipLaunchKernelGGL(k_icp_pass<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)g * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream));

@@ -68,6 +68,7 @@ struct o3d_ctx {
   float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
   size_t cap_local = 0;
   int tile_ok = 0;                // fp32 wave-tile prefilter usable on this grid
+  int use_tile = 0;               // run k_icp_search_tile instead of k_icp_search when tile_ok
   int tile_stats = 0;             // collect g_tile_stats
   int force_generic = 0;          // tests: run the generic per-lane fp64 pass instead of the wave-tile pass
   uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
@@ -79,6 +80,7 @@ struct o3d_ctx {
   uint32_t *src_perm = nullptr;    // processing position -> caller's index
   int32_t *corr_sorted = nullptr;  // per processing position
   int32_t *corr_out = nullptr;     // caller's order (device staging)
+  uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
   size_t cap_src = 0;
 
   // loop

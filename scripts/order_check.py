@@ -42,7 +42,7 @@ for dz in range(12):
         tot += np.where(m, cs[row + hi[:, 0] + 3] - cs[row + lo[:, 0]], 0)
 ok = ((hi[:, 0] - lo[:, 0] + 3) <= 10) & (nby <= 10) & (nbz <= 10) & (nby * nbz <= 32)
 print("ok %.3f  tot mean %.1f  frac tot<=96 %.3f  tiled %.3f" % (ok.mean(), tot[ok].mean(), (tot[ok] <= 96).mean(), (ok & (tot <= 96)).mean()))
-ctx.debug_set(False, True)
+ctx.debug_set(True, True)
 ctx.tile_stats(reset=True)
 sess.enqueue_step()
 print(ctx.tile_stats())

@@ -14,8 +14,8 @@ nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
 dev = torch.device("cuda", 0)
 d_src, d_tgt, d_nrm = (torch.from_numpy(a).to(dev) for a in (sc["source"], sc["target"], nrm))
 ctx = _lib.Context(0)
-for generic in (0, 1):
-    ctx.debug_set(bool(generic), True)
+for generic in (0, 2):
+    ctx._lib.o3d_debug_set(ctx.handle, generic, 0)
     sess = reg.IcpSession(ctx).setup(d_src, d_tgt, d_nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
                                      reg.ICPConvergenceCriteria(0, 0, 8))
     ctx.tile_stats(reset=True)
@@ -24,7 +24,7 @@ for generic in (0, 1):
         sess.enqueue_step()
     ms, k = sess.profile_read()
     st = ctx.tile_stats()
-    print("generic=%d kernel_ms=%.3f" % (generic, ms), st)
+    print("mode=%d (2 = tile search) pass_ms=%.3f" % (generic, ms), st)
     if st["wave_iters"]:
         print("  tiled %.3f  cand/tile %.1f  rows/tile %.1f  exact lane frac %.4f" % (
             st["tiled"] / st["wave_iters"], st["candidates"] / max(st["tiled"], 1), st["rows"] / max(st["tiled"], 1),
