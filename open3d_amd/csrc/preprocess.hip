@@ -1,9 +1,601 @@
-// placeholder until the preprocessing kernels land
+// Preprocessing kernels of the ICP path: PointCloud::VoxelDownSample (reference geometry/PointCloud.cpp:273-306) and
+// PointCloud::EstimateNormals (geometry/EstimateNormals.cpp:320-351 with ComputeNormal :215-252 and FastEigen3x3
+// :130-213).  Both are HBM-bound integer / gather work on the same sort + scan + cell-grid machinery as the ICP pass.
+#include <math.h>
+
+#include <algorithm>
+
 #include "o3d_internal.h"
-int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *, const double *, const double *, int64_t, double, int, double *,
-                               double *, double *, int32_t *, int64_t *) {
-  return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "VoxelDownSample: not built yet");
+
+namespace {
+
+int grid_for(int64_t n) {
+  int64_t g = (n + O3D_BLOCK - 1) / O3D_BLOCK;
+  if (g < 1) g = 1;
+  if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  return (int)g;
 }
-int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *, int64_t, int, int, double, int, double *, int) {
-  return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: not built yet");
+int ceil_log2(uint64_t v) {
+  int b = 0;
+  while (b < 63 && (1ull << b) < v) b++;
+  return b;
+}
+
+// =====================================================================================================================
+// VoxelDownSample
+// =====================================================================================================================
+struct VoxelParams {
+  double vmin[3];  // GetMinBound() - voxel_size / 2  (PointCloud.cpp:279)
+  double voxel;
+  int bx, by;      // key = (iz << (bx + by)) | (iy << bx) | ix
+};
+
+// voxel_index = int(floor((p - voxel_min_bound) / voxel_size)) per axis, true division (PointCloud.cpp:289-290).
+// Non-finite points have no voxel: sentinel key, sorted behind every real voxel.
+__global__ __launch_bounds__(O3D_BLOCK) void k_voxel_keys(const double *__restrict__ xyz, int64_t n, VoxelParams vp,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint64_t key = ~0ull;
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      const uint64_t ix = (uint64_t)(int)floor((x - vp.vmin[0]) / vp.voxel);
+      const uint64_t iy = (uint64_t)(int)floor((y - vp.vmin[1]) / vp.voxel);
+      const uint64_t iz = (uint64_t)(int)floor((z - vp.vmin[2]) / vp.voxel);
+      key = (iz << (vp.bx + vp.by)) | (iy << vp.bx) | ix;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_segment_heads(const uint64_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ head) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK)
+    head[p] = (p == 0 || keys[p] != keys[p - 1]) ? 1u : 0u;
+}
+
+// seg_id = exclusive scan of the head flags (so the head of segment m has seg_id == m); record segment starts.
+__global__ __launch_bounds__(O3D_BLOCK) void k_segment_starts(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_id,
+                                                               int64_t n, uint32_t *__restrict__ seg_start) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK)
+    if (p == 0 || keys[p] != keys[p - 1]) seg_start[seg_id[p]] = (uint32_t)p;
+}
+
+// One lane per voxel: AccumulatedPoint::AddPoint in input order (stable sort => ascending original index inside the
+// segment), then GetAveragePoint / Normal / Color (PointCloud.cpp:190-210).  Normals with a NaN component are skipped
+// in the numerator while the divisor stays the full count, as in the reference.
+__global__ __launch_bounds__(O3D_BLOCK) void k_voxel_reduce(const double *__restrict__ xyz, const double *__restrict__ nrm,
+                                                             const double *__restrict__ col, const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_start,
+                                                             int64_t m, int64_t n_finite, VoxelParams vp, double *__restrict__ out_xyz,
+                                                             double *__restrict__ out_nrm, double *__restrict__ out_col,
+                                                             int32_t *__restrict__ out_vox) {
+  for (int64_t v = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; v < m; v += (int64_t)gridDim.x * O3D_BLOCK) {
+    const uint32_t s = seg_start[v];
+    const uint32_t e = (v + 1 < m) ? seg_start[v + 1] : (uint32_t)n_finite;
+    double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+    for (uint32_t p = s; p < e; p++) {
+      const size_t i = vals[p];
+      sp[0] += xyz[3 * i]; sp[1] += xyz[3 * i + 1]; sp[2] += xyz[3 * i + 2];
+      if (nrm) {
+        const double a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+        if (!isnan(a) && !isnan(b) && !isnan(c)) { sn[0] += a; sn[1] += b; sn[2] += c; }
+      }
+      if (col) { sc[0] += col[3 * i]; sc[1] += col[3 * i + 1]; sc[2] += col[3 * i + 2]; }
+    }
+    const double cnt = (double)(e - s);
+    for (int d = 0; d < 3; d++) {
+      out_xyz[3 * v + d] = sp[d] / cnt;
+      if (nrm) out_nrm[3 * v + d] = sn[d] / cnt;
+      if (col) out_col[3 * v + d] = sc[d] / cnt;
+    }
+    if (out_vox) {
+      const uint64_t key = keys[s];
+      out_vox[3 * v] = (int32_t)(key & ((1ull << vp.bx) - 1));
+      out_vox[3 * v + 1] = (int32_t)((key >> vp.bx) & ((1ull << vp.by) - 1));
+      out_vox[3 * v + 2] = (int32_t)(key >> (vp.bx + vp.by));
+    }
+  }
+}
+
+// =====================================================================================================================
+// EstimateNormals
+// =====================================================================================================================
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// ComputeEigenvector0, EstimateNormals.cpp:40-68
+__device__ void eigvec0(const double (*A)[3], double eval0, double *out) {
+  const double row0[3] = {A[0][0] - eval0, A[0][1], A[0][2]};
+  const double row1[3] = {A[0][1], A[1][1] - eval0, A[1][2]};
+  const double row2[3] = {A[0][2], A[1][2], A[2][2] - eval0};
+  double r0xr1[3], r0xr2[3], r1xr2[3];
+  cross3(row0, row1, r0xr1);
+  cross3(row0, row2, r0xr2);
+  cross3(row1, row2, r1xr2);
+  const double d0 = r0xr1[0] * r0xr1[0] + r0xr1[1] * r0xr1[1] + r0xr1[2] * r0xr1[2];
+  const double d1 = r0xr2[0] * r0xr2[0] + r0xr2[1] * r0xr2[1] + r0xr2[2] * r0xr2[2];
+  const double d2 = r1xr2[0] * r1xr2[0] + r1xr2[1] * r1xr2[1] + r1xr2[2] * r1xr2[2];
+  double dmax = d0;
+  int imax = 0;
+  if (d1 > dmax) { dmax = d1; imax = 1; }
+  if (d2 > dmax) { imax = 2; }
+  if (imax == 0) { const double s = sqrt(d0); out[0] = r0xr1[0] / s; out[1] = r0xr1[1] / s; out[2] = r0xr1[2] / s; }
+  else if (imax == 1) { const double s = sqrt(d1); out[0] = r0xr2[0] / s; out[1] = r0xr2[1] / s; out[2] = r0xr2[2] / s; }
+  else { const double s = sqrt(d2); out[0] = r1xr2[0] / s; out[1] = r1xr2[1] / s; out[2] = r1xr2[2] / s; }
+}
+
+// ComputeEigenvector1, EstimateNormals.cpp:70-128
+__device__ void eigvec1(const double (*A)[3], const double *evec0, double eval1, double *out) {
+  double U[3], V[3];
+  if (fabs(evec0[0]) > fabs(evec0[1])) {
+    const double inv = 1 / sqrt(evec0[0] * evec0[0] + evec0[2] * evec0[2]);
+    U[0] = -evec0[2] * inv; U[1] = 0; U[2] = evec0[0] * inv;
+  } else {
+    const double inv = 1 / sqrt(evec0[1] * evec0[1] + evec0[2] * evec0[2]);
+    U[0] = 0; U[1] = evec0[2] * inv; U[2] = -evec0[1] * inv;
+  }
+  cross3(evec0, U, V);
+  const double AU[3] = {A[0][0] * U[0] + A[0][1] * U[1] + A[0][2] * U[2], A[0][1] * U[0] + A[1][1] * U[1] + A[1][2] * U[2],
+                        A[0][2] * U[0] + A[1][2] * U[1] + A[2][2] * U[2]};
+  const double AV[3] = {A[0][0] * V[0] + A[0][1] * V[1] + A[0][2] * V[2], A[0][1] * V[0] + A[1][1] * V[1] + A[1][2] * V[2],
+                        A[0][2] * V[0] + A[1][2] * V[1] + A[2][2] * V[2]};
+  double m00 = U[0] * AU[0] + U[1] * AU[1] + U[2] * AU[2] - eval1;
+  double m01 = U[0] * AV[0] + U[1] * AV[1] + U[2] * AV[2];
+  double m11 = V[0] * AV[0] + V[1] * AV[1] + V[2] * AV[2] - eval1;
+  const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+  if (a00 >= a11) {
+    if (fmax(a00, a01) > 0) {
+      if (a00 >= a01) { m01 /= m00; m00 = 1 / sqrt(1 + m01 * m01); m01 *= m00; }
+      else { m00 /= m01; m01 = 1 / sqrt(1 + m00 * m00); m00 *= m01; }
+      for (int d = 0; d < 3; d++) out[d] = m01 * U[d] - m00 * V[d];
+    } else {
+      for (int d = 0; d < 3; d++) out[d] = U[d];
+    }
+  } else {
+    if (fmax(a11, a01) > 0) {
+      if (a11 >= a01) { m01 /= m11; m11 = 1 / sqrt(1 + m01 * m01); m01 *= m11; }
+      else { m11 /= m01; m01 = 1 / sqrt(1 + m11 * m11); m11 *= m01; }
+      for (int d = 0; d < 3; d++) out[d] = m11 * U[d] - m01 * V[d];
+    } else {
+      for (int d = 0; d < 3; d++) out[d] = U[d];
+    }
+  }
+}
+
+// FastEigen3x3, EstimateNormals.cpp:130-213 (A.maxCoeff() is the SIGNED maximum, :137)
+__device__ void fast_eigen3x3(const double *cov, double *normal) {
+  double A[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i][j] = cov[i * 3 + j];
+  double max_coeff = A[0][0];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      if (A[i][j] > max_coeff) max_coeff = A[i][j];
+  if (max_coeff == 0) { normal[0] = normal[1] = normal[2] = 0; return; }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i][j] /= max_coeff;
+  const double norm = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+  if (norm > 0) {
+    double eval[3], evec0[3], evec1[3], evec2[3];
+    const double q = (A[0][0] + A[1][1] + A[2][2]) / 3;
+    const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
+    const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+    const double c00 = b11 * b22 - A[1][2] * A[1][2];
+    const double c01 = A[0][1] * b22 - A[1][2] * A[0][2];
+    const double c02 = A[0][1] * A[1][2] - b11 * A[0][2];
+    const double det = (b00 * c00 - A[0][1] * c01 + A[0][2] * c02) / (p * p * p);
+    double half_det = det * 0.5;
+    half_det = fmin(fmax(half_det, -1.0), 1.0);
+    const double angle = acos(half_det) / (double)3;
+    const double two_thirds_pi = 2.09439510239319549;
+    const double beta2 = cos(angle) * 2;
+    const double beta0 = cos(angle + two_thirds_pi) * 2;
+    const double beta1 = -(beta0 + beta2);
+    eval[0] = q + p * beta0;
+    eval[1] = q + p * beta1;
+    eval[2] = q + p * beta2;
+    if (half_det >= 0) {
+      eigvec0(A, eval[2], evec2);
+      if (eval[2] < eval[0] && eval[2] < eval[1]) { for (int d = 0; d < 3; d++) normal[d] = evec2[d]; return; }
+      eigvec1(A, evec2, eval[1], evec1);
+      if (eval[1] < eval[0] && eval[1] < eval[2]) { for (int d = 0; d < 3; d++) normal[d] = evec1[d]; return; }
+      cross3(evec1, evec2, evec0);
+      for (int d = 0; d < 3; d++) normal[d] = evec0[d];
+    } else {
+      eigvec0(A, eval[0], evec0);
+      if (eval[0] < eval[1] && eval[0] < eval[2]) { for (int d = 0; d < 3; d++) normal[d] = evec0[d]; return; }
+      eigvec1(A, evec0, eval[1], evec1);
+      if (eval[1] < eval[0] && eval[1] < eval[2]) { for (int d = 0; d < 3; d++) normal[d] = evec1[d]; return; }
+      cross3(evec0, evec1, evec2);
+      for (int d = 0; d < 3; d++) normal[d] = evec2[d];
+    }
+  } else {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) A[i][j] *= max_coeff;
+    if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) { normal[0] = 1; normal[1] = 0; normal[2] = 0; }
+    else if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) { normal[0] = 0; normal[1] = 1; normal[2] = 0; }
+    else { normal[0] = 0; normal[1] = 0; normal[2] = 1; }
+  }
+}
+
+constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
+constexpr int kMaxKnn = 64;
+
+// k-best list of one lane, ascending by (d2, index) -- the order FLANN returns and ComputeNormal sums in.
+struct KList {
+  double *d2;     // LDS, stride kNrmBlock
+  uint32_t *pos;  // LDS, stride kNrmBlock: position in tgt_sorted
+  uint32_t *idx;  // LDS, stride kNrmBlock: original index (tie-break)
+  int cap, count;
+  double thr;     // strict bound on d2 (INFINITY for pure KNN)
+};
+
+__device__ __forceinline__ double klist_worst(const KList &l) {
+  return (l.count == l.cap) ? l.d2[(l.cap - 1) * kNrmBlock] : l.thr;
+}
+
+__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t id, uint32_t pos) {
+  if (!(d < l.thr)) return;
+  int i;
+  if (l.count == l.cap) {
+    const double wd = l.d2[(l.cap - 1) * kNrmBlock];
+    const uint32_t wi = l.idx[(l.cap - 1) * kNrmBlock];
+    if (!(d < wd || (d == wd && id < wi))) return;
+    i = l.cap - 1;
+  } else {
+    i = l.count++;
+  }
+  while (i > 0) {
+    const double pd = l.d2[(i - 1) * kNrmBlock];
+    const uint32_t pi = l.idx[(i - 1) * kNrmBlock];
+    if (!(d < pd || (d == pd && id < pi))) break;
+    l.d2[i * kNrmBlock] = pd;
+    l.idx[i * kNrmBlock] = pi;
+    l.pos[i * kNrmBlock] = l.pos[(i - 1) * kNrmBlock];
+    i--;
+  }
+  l.d2[i * kNrmBlock] = d;
+  l.idx[i * kNrmBlock] = id;
+  l.pos[i * kNrmBlock] = pos;
+}
+
+// Per point: neighbours by KNN / radius / hybrid search over the cloud's own cell grid, cumulants in neighbour order,
+// covariance, FastEigen3x3, fallbacks and orientation against an existing normal (EstimateNormals.cpp:330-350).
+//   MODE 0 KNN: shells of cells are added until the k-th distance is inside the searched cube.
+//   MODE 1 Radius: every point with d2 < thr in the 3x3x3 block; cumulants summed in traversal order (the reference
+//          sums in ascending distance: same set, rounding-level difference only).
+//   MODE 2 Hybrid: the max_nn nearest with d2 < thr.
+template <int MODE>
+__global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *__restrict__ pts, int64_t n_grid,
+                                                                 const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
+                                                                 double thr, double *__restrict__ normals, int has_normals) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  KList l;
+  l.d2 = reinterpret_cast<double *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.idx = l.pos + kNrmBlock * (size_t)knn;
+  l.cap = knn;
+  l.thr = (MODE == 0) ? INFINITY : thr;
+  const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
+
+  for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
+    const double4 q = pts[p];
+    const size_t qi = (size_t)__double_as_longlong(q.w);
+    const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    l.count = 0;
+    int count = 0;                                  // MODE 1
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // cumulants
+    for (int R = 1;; R++) {
+      // shell R of the cube around the query's cell (R == 1: the whole 3x3x3 block)
+      for (int dz = -R; dz <= R; dz++) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= gp.nz) continue;
+        for (int dy = -R; dy <= R; dy++) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= gp.ny) continue;
+          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+          const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
+          const int nseg = face ? 1 : 2;
+          for (int sgi = 0; sgi < nseg; sgi++) {
+            int xa, xb;  // unpadded cell range of this piece of the row
+            if (face) { xa = cx - R; xb = cx + R; }
+            else if (sgi == 0) { xa = xb = cx - R; }
+            else { xa = xb = cx + R; }
+            xa = max(xa, -1); xb = min(xb, gp.nx);
+            if (xa > xb) continue;
+            const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+            for (uint32_t j = s; j < e; j++) {
+              const double4 t = pts[j];
+              const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+              double d2 = ddx * ddx;
+              d2 = d2 + ddy * ddy;
+              d2 = d2 + ddz * ddz;
+              if (MODE == 1) {
+                if (d2 < thr) {
+                  count++;
+                  c[0] += t.x; c[1] += t.y; c[2] += t.z;
+                  c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+                  c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+                }
+              } else if (d2 <= klist_worst(l)) {
+                klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+              }
+            }
+          }
+        }
+      }
+      if (MODE != 0) break;  // h >= radius: the 3x3x3 block is complete
+      // KNN: every unsearched point is at least R*h away (minus rounding); done once the k-th distance is inside
+      if (R >= max_dim) break;
+      if (l.count == l.cap) {
+        const double reach = (double)R * gp.h * (1.0 - 1e-6);
+        if (klist_worst(l) <= reach * reach) break;
+      }
+    }
+    int k = count;
+    if (MODE != 1) {
+      k = l.count;
+      for (int i = 0; i < k; i++) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
+        const double4 t = pts[l.pos[i * kNrmBlock]];
+        c[0] += t.x; c[1] += t.y; c[2] += t.z;
+        c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+        c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+      }
+    }
+    double nv[3] = {0.0, 0.0, 1.0};
+    if (k >= 3) {
+      for (int i = 0; i < 9; i++) c[i] /= (double)k;
+      double cov[9];
+      cov[0] = c[3] - c[0] * c[0];
+      cov[4] = c[6] - c[1] * c[1];
+      cov[8] = c[8] - c[2] * c[2];
+      cov[1] = cov[3] = c[4] - c[0] * c[1];
+      cov[2] = cov[6] = c[5] - c[0] * c[2];
+      cov[5] = cov[7] = c[7] - c[1] * c[2];
+      fast_eigen3x3(cov, nv);
+      if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
+        if (has_normals) { nv[0] = normals[3 * qi]; nv[1] = normals[3 * qi + 1]; nv[2] = normals[3 * qi + 2]; }
+        else { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+      }
+      if (has_normals && nv[0] * normals[3 * qi] + nv[1] * normals[3 * qi + 1] + nv[2] * normals[3 * qi + 2] < 0.0) {
+        nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0;
+      }
+    }
+    normals[3 * qi] = nv[0]; normals[3 * qi + 1] = nv[1]; normals[3 * qi + 2] = nv[2];
+  }
+}
+
+// Non-finite points are not in the grid: FLANN finds no finite-distance neighbour for them -> fewer than 3 -> (0,0,1).
+__global__ __launch_bounds__(O3D_BLOCK) void k_normals_nonfinite(const double *__restrict__ xyz, int64_t n, double *__restrict__ normals) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) { normals[3 * i] = 0.0; normals[3 * i + 1] = 0.0; normals[3 * i + 2] = 1.0; }
+  }
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_count_heads(const uint32_t *__restrict__ keys, int64_t n, uint32_t sentinel,
+                                                            unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK)
+    if (keys[p] != sentinel && (p == 0 || keys[p] != keys[p - 1])) c++;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, O3D_WAVE);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+}  // namespace
+
+// keys of the last o3d_build_target_grid call stay sorted in scratch slot 1: number of occupied cells
+static int count_occupied_cells(o3d_ctx *ctx, int64_t n, int64_t *out) {
+  void *cnt;
+  O3D_TRY(o3d_scratch(ctx, 7, 256, &cnt));
+  O3D_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_count_heads, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint32_t *)ctx->scratch[1], n,
+                     ctx->gp.ncell, (unsigned long long *)cnt);
+  unsigned long long *h = (unsigned long long *)ctx->pinned;
+  O3D_HIP(ctx, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = (int64_t)*h;
+  return O3D_OK;
+}
+
+int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                              double *normals, int has_normals) {
+  if (n < 0 || (n > 0 && (!xyz || !normals))) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: null buffer");
+  if (search_type < 0 || search_type > 2) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: unknown search type %d", search_type);
+  if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: more than 2^31-1 points");
+  if (n == 0) return O3D_OK;
+  ctx->icp_ready = 0;  // the context's target grid is rebuilt for this cloud
+  const size_t bytes = sizeof(double) * 3 * (size_t)n;
+  const double *d_xyz = xyz;
+  double *d_nrm = normals;
+  void *sx = nullptr, *sn = nullptr;
+  if (mem == O3D_MEM_HOST) {
+    O3D_HIP(ctx, hipMalloc(&sx, bytes));
+    hipError_t e = hipMalloc(&sn, bytes);
+    if (e != hipSuccess) { (void)hipFree(sx); return o3d_fail(ctx, O3D_ERR_OOM, "EstimateNormals: %s", hipGetErrorString(e)); }
+    d_xyz = (const double *)sx;
+    d_nrm = (double *)sn;
+  }
+  auto cleanup = [&]() {
+    if (sx) (void)hipFree(sx);
+    if (sn) (void)hipFree(sn);
+  };
+  auto run = [&]() -> int {
+    if (mem == O3D_MEM_HOST) {
+      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      if (has_normals) O3D_HIP(ctx, hipMemcpyAsync(sn, normals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const bool degenerate = (search_type != O3D_SEARCH_RADIUS && knn < 3) || (search_type != O3D_SEARCH_KNN && !(radius > 0.0));
+    if (search_type != O3D_SEARCH_RADIUS && knn > kMaxKnn)
+      return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: knn/max_nn > %d is not on the device path", kMaxKnn);
+    double h;
+    if (search_type == O3D_SEARCH_KNN) {
+      // cell size from the cloud's density: aim at ~8 points per occupied cell (two trial builds at most four times)
+      double bb[6];
+      int64_t nf = 0;
+      O3D_TRY(o3d_bounds(ctx, d_xyz, n, bb, &nf));
+      const double ext = std::max(std::max(bb[3] - bb[0], bb[4] - bb[1]), std::max(bb[5] - bb[2], 1e-300));
+      h = ext * sqrt(8.0 / (double)std::max<int64_t>(nf, 1));
+      if (!(h > 0.0)) h = 1.0;
+      for (int trial = 0; trial < 4 && nf > 0; trial++) {
+        O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, h));
+        int64_t occ = 0;
+        O3D_TRY(count_occupied_cells(ctx, n, &occ));
+        const double pop = (double)nf / (double)std::max<int64_t>(occ, 1);
+        if (pop >= 4.0 && pop <= 16.0) break;
+        if (ctx->gp.h > h * 1.01 && pop > 16.0) break;  // the dense-table budget already coarsened the grid
+        h = ctx->gp.h / (1.0 + 1e-5) * pow(8.0 / pop, 1.0 / 2.5);
+      }
+    } else {
+      h = radius;
+    }
+    // degenerate: knn < 3 or an empty radius -- no point can collect 3 neighbours, every normal becomes (0, 0, 1)
+    // (:347-349); run the hybrid kernel with an empty acceptance threshold
+    O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, degenerate ? 1.0 : h));
+    const int64_t ng = ctx->n_tgt_grid;
+    const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126,148
+    const int kk = degenerate ? 1 : (search_type == O3D_SEARCH_RADIUS ? 1 : knn);
+    const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)kk;
+    int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
+    g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+    if (ng > 0) {
+      if (degenerate) {
+        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
+                           ctx->cell_start, ctx->gp, 1, 0.0, d_nrm, has_normals);
+      } else if (search_type == O3D_SEARCH_KNN) {
+        hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
+                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+      } else if (search_type == O3D_SEARCH_RADIUS) {
+        hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
+                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+      } else {
+        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
+                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+      }
+    }
+    if (ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);
+    O3D_HIP(ctx, hipGetLastError());
+    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(normals, d_nrm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return O3D_OK;
+  };
+  const int st = run();
+  cleanup();
+  return st;
+}
+
+int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
+                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m) {
+  if (out_m) *out_m = 0;
+  if (!(voxel > 0.0)) return o3d_fail(ctx, O3D_ERR_VOXEL_SIZE, "%s", o3d_status_string(O3D_ERR_VOXEL_SIZE));  // :275-277
+  if (n < 0 || (n > 0 && (!xyz || !out_xyz)) || (nrm && !out_nrm) || (col && !out_col) || !out_m)
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "VoxelDownSample: null buffer");
+  if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "VoxelDownSample: more than 2^31-1 points");
+  if (n == 0) return O3D_OK;
+  const size_t bytes = sizeof(double) * 3 * (size_t)n;
+  void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  auto cleanup = [&]() {
+    for (void *p : stage)
+      if (p) (void)hipFree(p);
+  };
+  auto run = [&]() -> int {
+    const double *d_xyz = xyz, *d_nrm = nrm, *d_col = col;
+    double *o_xyz = out_xyz, *o_nrm = out_nrm, *o_col = out_col;
+    int32_t *o_vox = out_vox;
+    if (mem == O3D_MEM_HOST) {
+      O3D_HIP(ctx, hipMalloc(&stage[0], bytes));
+      O3D_HIP(ctx, hipMemcpyAsync(stage[0], xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      d_xyz = (const double *)stage[0];
+      if (nrm) {
+        O3D_HIP(ctx, hipMalloc(&stage[1], bytes));
+        O3D_HIP(ctx, hipMemcpyAsync(stage[1], nrm, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_nrm = (const double *)stage[1];
+      }
+      if (col) {
+        O3D_HIP(ctx, hipMalloc(&stage[2], bytes));
+        O3D_HIP(ctx, hipMemcpyAsync(stage[2], col, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_col = (const double *)stage[2];
+      }
+    }
+    double bb[6];
+    int64_t nf = 0;
+    O3D_TRY(o3d_bounds(ctx, d_xyz, n, bb, &nf));
+    if (nf == 0) return O3D_OK;
+    VoxelParams vp;
+    double ext = 0.0;
+    uint64_t maxi[3];
+    for (int d = 0; d < 3; d++) {
+      vp.vmin[d] = bb[d] - voxel * 0.5;                       // :279
+      const double vmax = bb[3 + d] + voxel * 0.5;            // :280
+      ext = std::max(ext, vmax - vp.vmin[d]);
+      maxi[d] = (uint64_t)floor((bb[3 + d] - vp.vmin[d]) / voxel) + 1;
+    }
+    if (voxel * (double)INT32_MAX < ext) return o3d_fail(ctx, O3D_ERR_VOXEL_TOO_SMALL, "%s", o3d_status_string(O3D_ERR_VOXEL_TOO_SMALL));
+    vp.voxel = voxel;
+    vp.bx = ceil_log2(maxi[0] + 1);
+    vp.by = ceil_log2(maxi[1] + 1);
+    const int bz = ceil_log2(maxi[2] + 1);
+    if (vp.bx + vp.by + bz > 63)
+      return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "VoxelDownSample: voxel lattice needs %d key bits (> 63)", vp.bx + vp.by + bz);
+
+    const size_t ntiles = o3d_sort_num_tiles(n);
+    const size_t nh = 256 * ntiles;
+    void *keys, *vals, *tkeys, *tvals, *hist, *head, *bsum;
+    O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint64_t) * (size_t)n, &keys));
+    O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
+    O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
+    O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    O3D_TRY(o3d_scratch(ctx, 6, sizeof(uint32_t) * (o3d_scan_num_blocks(n + 1) + 8), &bsum));
+    O3D_TRY(o3d_scratch(ctx, 0, sizeof(uint32_t) * ((size_t)n + 8), &head));
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, vp, (uint64_t *)keys, (uint32_t *)vals);
+    // 64 key bits so that the sentinel (all ones) of non-finite points sorts last
+    O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, (uint32_t *)vals, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
+                               nf < n ? 64 : vp.bx + vp.by + bz));
+    // segments over the finite prefix [0, nf)
+    hipLaunchKernelGGL(k_segment_heads, dim3(grid_for(nf)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys, nf, (uint32_t *)head);
+    O3D_HIP(ctx, hipMemsetAsync((uint32_t *)head + nf, 0, sizeof(uint32_t), ctx->stream));
+    O3D_TRY(o3d_exclusive_scan_u32(ctx, (uint32_t *)head, (uint32_t *)bsum, nf + 1));
+    uint32_t *hm = (uint32_t *)ctx->pinned;
+    O3D_HIP(ctx, hipMemcpyAsync(hm, (uint32_t *)head + nf, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t m = (int64_t)*hm;
+    // segment starts reuse the tmp-vals buffer (free after the sort)
+    uint32_t *seg_start = (uint32_t *)tvals;
+    hipLaunchKernelGGL(k_segment_starts, dim3(grid_for(nf)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys,
+                       (const uint32_t *)head, nf, seg_start);
+    if (mem == O3D_MEM_HOST) {
+      const size_t ob = sizeof(double) * 3 * (size_t)m;
+      O3D_HIP(ctx, hipMalloc(&stage[3], ob));
+      o_xyz = (double *)stage[3];
+      if (nrm) { O3D_HIP(ctx, hipMalloc(&stage[4], ob)); o_nrm = (double *)stage[4]; }
+      if (col) { O3D_HIP(ctx, hipMalloc(&stage[5], ob)); o_col = (double *)stage[5]; }
+      if (out_vox) { O3D_HIP(ctx, hipMalloc(&stage[6], sizeof(int32_t) * 3 * (size_t)m)); o_vox = (int32_t *)stage[6]; }
+    }
+    hipLaunchKernelGGL(k_voxel_reduce, dim3(grid_for(m)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, d_nrm, d_col, (const uint64_t *)keys,
+                       (const uint32_t *)vals, (const uint32_t *)seg_start, m, nf, vp, o_xyz, nrm ? o_nrm : nullptr,
+                       col ? o_col : nullptr, o_vox);
+    O3D_HIP(ctx, hipGetLastError());
+    if (mem == O3D_MEM_HOST) {
+      const size_t ob = sizeof(double) * 3 * (size_t)m;
+      O3D_HIP(ctx, hipMemcpyAsync(out_xyz, o_xyz, ob, hipMemcpyDeviceToHost, ctx->stream));
+      if (nrm) O3D_HIP(ctx, hipMemcpyAsync(out_nrm, o_nrm, ob, hipMemcpyDeviceToHost, ctx->stream));
+      if (col) O3D_HIP(ctx, hipMemcpyAsync(out_col, o_col, ob, hipMemcpyDeviceToHost, ctx->stream));
+      if (out_vox) O3D_HIP(ctx, hipMemcpyAsync(out_vox, o_vox, sizeof(int32_t) * 3 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_m = m;
+    return O3D_OK;
+  };
+  const int st = run();
+  cleanup();
+  return st;
 }

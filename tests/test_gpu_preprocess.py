@@ -1,0 +1,140 @@
+"""GPU parity tests of the preprocessing kernels (VoxelDownSample, EstimateNormals) against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _geo():
+    from open3d_amd import geometry
+    return geometry
+
+
+@pytest.mark.parametrize("n,voxel_s", [(20000, 2.0), (50000, 5.0), (3000, 0.3)])
+def test_voxel_down_sample_bit_exact(ctx, oracle, n, voxel_s):
+    """Per-voxel sums run in input order on both sides: points / normals / colours must be IDENTICAL doubles."""
+    geometry = _geo()
+    sc = make_scene(n, n, cfg_id=21)
+    rng = np.random.default_rng(3)
+    pts = sc["target"]
+    nrm = rng.normal(size=pts.shape)
+    nrm[::17, 1] = np.nan  # NaN normals are skipped in the sum but counted in the divisor (PointCloud.cpp:193-208)
+    col = rng.random(pts.shape)
+    v = voxel_s * sc["spacing"]
+    got, vox = geometry.PointCloud(pts, nrm, col).VoxelDownSample(v, ctx=ctx, return_voxel_index=True)
+    rp, rn, rc, rv = oracle.voxel_down_sample(pts, v, nrm, col)
+    assert len(got.points_) == len(rp)
+    assert np.array_equal(vox, rv)
+    assert np.array_equal(got.points_, rp)
+    assert np.array_equal(got.normals_, rn, equal_nan=True)
+    assert np.array_equal(got.colors_, rc)
+
+
+def test_voxel_down_sample_points_only_and_edges(ctx, oracle):
+    geometry = _geo()
+    rng = np.random.default_rng(0)
+    pts = rng.random((5000, 3)) * np.array([3.0, 1.0, 0.2]) - 1.0
+    for v in (0.05, 0.5, 10.0):
+        got, vox = geometry.PointCloud(pts).VoxelDownSample(v, ctx=ctx, return_voxel_index=True)
+        rp, _, _, rv = oracle.voxel_down_sample(pts, v)
+        assert np.array_equal(vox, rv) and np.array_equal(got.points_, rp)
+        assert not got.HasNormals() and not got.HasColors()
+    one = geometry.PointCloud(pts[:1]).VoxelDownSample(0.1, ctx=ctx)
+    assert np.array_equal(one.points_, pts[:1])
+    empty = geometry.PointCloud(np.zeros((0, 3))).VoxelDownSample(0.1, ctx=ctx)
+    assert len(empty.points_) == 0
+
+
+def test_voxel_down_sample_errors(ctx):
+    geometry = _geo()
+    from open3d_amd import _lib
+    pc = geometry.PointCloud(np.random.default_rng(1).random((100, 3)) * 1e6)
+    with pytest.raises(_lib.O3DError, match="voxel_size <= 0"):
+        pc.VoxelDownSample(0.0, ctx=ctx)
+    with pytest.raises(_lib.O3DError, match="voxel_size is too small"):
+        pc.VoxelDownSample(1e-5, ctx=ctx)
+
+
+def _normals_close(got, ref, tol=1e-9):
+    d = np.abs(got - ref).max(axis=1)
+    return d < tol
+
+
+@pytest.mark.parametrize("mode", ["knn", "hybrid", "radius"])
+@pytest.mark.parametrize("cloud", ["surface", "volume"])
+def test_estimate_normals_matches_oracle(ctx, oracle, mode, cloud):
+    """Same neighbour sets (exact k-best by (d2, index)), cumulants summed in the same order for knn / hybrid:
+    normals agree to 1e-9 (libm acos / cos differ in the last ulp between host and device)."""
+    geometry = _geo()
+    if cloud == "surface":
+        sc = make_scene(30000, 30000, cfg_id=8)
+        pts, s = sc["target"], sc["spacing"]
+    else:
+        rng = np.random.default_rng(4)
+        pts = rng.random((20000, 3))
+        s = (1.0 / 20000) ** (1.0 / 3.0)
+    if mode == "knn":
+        sp, args = geometry.KDTreeSearchParamKNN(30), (oracle.KNN, 30, 0.0)
+    elif mode == "hybrid":
+        sp, args = geometry.KDTreeSearchParamHybrid(4 * s, 30), (oracle.HYBRID, 30, 4 * s)
+    else:
+        sp, args = geometry.KDTreeSearchParamRadius(2.5 * s), (oracle.RADIUS, 0, 2.5 * s)
+    pc = geometry.PointCloud(pts)
+    pc.EstimateNormals(sp, ctx=ctx)
+    ref = oracle.estimate_normals(pts, *args)
+    ok = _normals_close(pc.normals_, ref, 1e-9 if mode != "radius" else 1e-7)
+    assert ok.mean() > 0.9999, "mismatching normals: %d of %d" % ((~ok).sum(), len(ok))
+    # the few allowed outliers must be ill-conditioned eigen problems, not wrong neighbourhoods: still unit vectors
+    assert np.allclose(np.linalg.norm(pc.normals_, axis=1), 1.0, atol=1e-9)
+
+
+def test_estimate_normals_knn_small_k_and_sparse(ctx, oracle):
+    geometry = _geo()
+    rng = np.random.default_rng(6)
+    pts = np.concatenate([rng.random((3000, 3)), rng.random((50, 3)) * 50.0 + 10.0])  # dense blob + far sparse points
+    for k in (3, 7, 30):
+        pc = geometry.PointCloud(pts)
+        pc.EstimateNormals(geometry.KDTreeSearchParamKNN(k), ctx=ctx)
+        ref = oracle.estimate_normals(pts, oracle.KNN, k, 0.0)
+        assert _normals_close(pc.normals_, ref).mean() > 0.999
+
+
+def test_estimate_normals_fallbacks_and_orientation(ctx, oracle):
+    geometry = _geo()
+    rng = np.random.default_rng(7)
+    pts = rng.random((4000, 3))
+    # < 3 neighbours -> (0, 0, 1)
+    pc = geometry.PointCloud(pts)
+    pc.EstimateNormals(geometry.KDTreeSearchParamKNN(2), ctx=ctx)
+    assert np.all(pc.normals_ == np.array([0.0, 0.0, 1.0]))
+    pc.EstimateNormals(geometry.KDTreeSearchParamRadius(1e-6), ctx=ctx)
+    assert np.all(pc.normals_ == np.array([0.0, 0.0, 1.0]))
+    two = geometry.PointCloud(pts[:2])
+    two.EstimateNormals(ctx=ctx)
+    assert np.all(two.normals_ == np.array([0.0, 0.0, 1.0]))
+    # existing normals: result flipped to agree with them (EstimateNormals.cpp:343-345)
+    prior = rng.normal(size=pts.shape)
+    pc2 = geometry.PointCloud(pts, normals=prior.copy())
+    pc2.EstimateNormals(geometry.KDTreeSearchParamKNN(20), ctx=ctx)
+    ref = oracle.estimate_normals(pts, oracle.KNN, 20, 0.0, normals=prior)
+    assert _normals_close(pc2.normals_, ref).mean() > 0.999
+    assert np.all((pc2.normals_ * prior).sum(1) >= -1e-12)
+
+
+def test_pipeline_downsample_normals_icp(ctx, oracle):
+    """Config-3 shaped pipeline at test size: VoxelDownSample both clouds -> EstimateNormals(target) -> P2Plane ICP."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(60000, 60000, cfg_id=13)
+    v = 2 * sc["spacing"]
+    src = geometry.PointCloud(sc["source"]).VoxelDownSample(v, ctx=ctx)
+    tgt = geometry.PointCloud(sc["target"]).VoxelDownSample(v, ctx=ctx)
+    tgt.EstimateNormals(geometry.KDTreeSearchParamKNN(30), ctx=ctx)
+    got = reg.RegistrationICP(src, tgt, 2 * v, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx)
+    # oracle on the same preprocessed clouds (its own preprocessing is covered by the tests above)
+    ref = oracle.registration_icp(src.points_, tgt.points_, 2 * v, None, 2, tgt.normals_)
+    assert got.iterations_ == ref.iterations
+    assert np.array_equal(got.corr_, ref.corr)
+    assert np.max(np.abs(got.transformation_ - ref.transformation)) < 1e-6
