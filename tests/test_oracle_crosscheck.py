@@ -1,0 +1,268 @@
+"""CPU suite: the oracle (oracle/o3d_oracle.c) against independent numpy / scipy computations.
+
+The reference ships no tests or golden vectors, so these cross-checks -- together with the
+reference call sites cited in the oracle -- are what pins the restatement ("parity unpinned" by reference fixtures).
+"""
+import numpy as np
+import pytest
+
+from conftest import make_scene
+
+
+def _np_brute(src, tgt, thr):
+    d = src[:, None, :] - tgt[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]  # ((dx*dx)+dy*dy)+dz*dz, no FMA
+    j = np.argmin(d2, axis=1)  # first minimum = lowest index on ties
+    m = d2[np.arange(len(src)), j]
+    return np.where(m < thr, j, -1).astype(np.int32), m
+
+
+def test_radius_threshold_known_answers(oracle):
+    # (double)(float)(r*r), geometry/KDTreeFlann.cpp:148 -- values from SURVEY.md section 8c
+    assert oracle.radius_threshold(0.05) == 0.0024999999441206455
+    assert oracle.radius_threshold(0.075) == 0.005625000223517418
+    assert oracle.radius_threshold(0.05) < 0.05 * 0.05 < 0.075 * 0.075 < oracle.radius_threshold(0.075)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_correspondences_vs_numpy_bruteforce(oracle, seed):
+    sc = make_scene(1500, 2000, cfg_id=100 + seed)
+    r = 2.5 * sc["spacing"]
+    want, d2 = _np_brute(sc["source"], sc["target"], oracle.radius_threshold(r))
+    for brute in (False, True):
+        corr, nc, sd2, fit, rmse = oracle.correspondences(sc["source"], sc["target"], r, brute=brute)
+        assert np.array_equal(corr, want)
+        assert nc == (want >= 0).sum() and fit == nc / len(want)
+        assert abs(sd2 - d2[want >= 0].sum()) <= 1e-12 * sd2
+        assert abs(rmse - np.sqrt(d2[want >= 0].sum() / nc)) <= 1e-12 * rmse
+
+
+def test_correspondences_ties_lowest_index_and_nan(oracle):
+    rng = np.random.default_rng(0)
+    tgt = rng.random((300, 3))
+    tgt = np.concatenate([tgt, tgt[:40]])  # duplicates: the lower index must win
+    src = tgt[:40] + 1e-3
+    src[3] = np.nan
+    for brute in (False, True):
+        corr = oracle.correspondences(src, tgt, 0.1, brute=brute)[0]
+        assert corr[3] == -1
+        assert np.all(corr[np.arange(40) != 3] < 300)
+
+
+def test_correspondences_vs_scipy_ckdtree_100k(oracle):
+    from scipy.spatial import cKDTree
+    sc = make_scene(100_000, 100_000, cfg_id=1)
+    r = 3 * sc["spacing"]
+    corr, nc, sd2, fit, rmse = oracle.correspondences(sc["source"], sc["target"], r)
+    d, j = cKDTree(sc["target"]).query(sc["source"], k=1, distance_upper_bound=np.sqrt(oracle.radius_threshold(r)))
+    want = np.where(np.isfinite(d), j, -1)
+    assert (corr != want).mean() < 1e-5  # scipy rounds distances differently: only ulp-level ties may differ
+    assert abs(fit - np.isfinite(d).mean()) < 1e-5
+
+
+def test_kdtree_knn_radius_vs_bruteforce(oracle):
+    rng = np.random.default_rng(5)
+    pts = rng.random((3000, 3))
+    for q in pts[:25]:
+        for st, knn, rad in [(oracle.KNN, 30, 0.0), (oracle.HYBRID, 12, 0.15), (oracle.RADIUS, 0, 0.12)]:
+            ia, da = oracle.neighbors(pts, q, st, knn, rad, brute=False)
+            ib, db = oracle.neighbors(pts, q, st, knn, rad, brute=True)
+            if st == oracle.RADIUS:  # brute returns its set in (d2, idx) order as well
+                d2 = ((q - pts) ** 2)
+                d2 = (d2[:, 0] + d2[:, 1]) + d2[:, 2]
+                want = np.nonzero(d2 < oracle.radius_threshold(rad))[0]
+                assert set(ia.tolist()) == set(want.tolist())
+                assert np.all(np.diff(da) >= 0)
+            else:
+                assert np.array_equal(ia, ib) and np.array_equal(da, db)
+
+
+def test_transform_points_operation_order(oracle):
+    rng = np.random.default_rng(2)
+    T = np.eye(4)
+    T[:3, :3] = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    T[:3, 3] = rng.normal(size=3)
+    p = rng.normal(size=(1000, 3)) * 10
+    out = oracle.transform_points(T, p)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    rows = [((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3] * 1.0 for r in range(4)]
+    want = np.stack([rows[0] / rows[3], rows[1] / rows[3], rows[2] / rows[3]], axis=1)
+    assert np.array_equal(out, want)
+
+
+def test_is_identity_semantics(oracle):
+    assert oracle.is_identity(np.eye(4))
+    T = np.eye(4); T[0, 3] = 1e-13
+    assert oracle.is_identity(T)
+    T[0, 3] = 1e-11
+    assert not oracle.is_identity(T)
+    T = np.eye(4); T[1, 1] = 1 + 1e-11
+    assert not oracle.is_identity(T)
+
+
+def test_ldlt_and_vec6(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        J = rng.normal(size=(50, 6))
+        A, b = J.T @ J, rng.normal(size=6)
+        x = oracle.ldlt_solve(A, b)
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    # singular direction: Eigen's LDLT solve zeroes the component instead of dividing by 0
+    A = np.diag([1.0, 2.0, 0.0, 3.0, 4.0, 5.0])
+    x = oracle.ldlt_solve(A, np.ones(6))
+    assert np.allclose(x, [1, 0.5, 0, 1 / 3, 0.25, 0.2])
+    v = rng.normal(size=6) * 0.3
+    T = oracle.vec6_to_mat4(v)
+    cx, sx, cy, sy, cz, sz = np.cos(v[0]), np.sin(v[0]), np.cos(v[1]), np.sin(v[1]), np.cos(v[2]), np.sin(v[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    assert np.allclose(T[:3, :3], Rz @ Ry @ Rx, atol=1e-15)  # utility/Eigen.cpp:92-94
+    assert np.array_equal(T[:3, 3], v[3:]) and np.array_equal(T[3], [0, 0, 0, 1])
+
+
+def test_svd3_and_umeyama(oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        A = rng.normal(size=(3, 3))
+        U, S, V = oracle.svd3(A)
+        assert np.allclose(U @ np.diag(S) @ V.T, A, atol=1e-13)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-13) and np.allclose(V.T @ V, np.eye(3), atol=1e-13)
+        assert np.allclose(S, np.linalg.svd(A, compute_uv=False), atol=1e-13)
+    U, S, V = oracle.svd3(np.diag([2.0, 1.0, 0.0]))  # rank deficient
+    assert np.allclose(U.T @ U, np.eye(3), atol=1e-13) and np.allclose(S, [2, 1, 0])
+
+    def umeyama(src, dst, scaling):  # Eigen/src/Geometry/Umeyama.h
+        ms, md = src.mean(0), dst.mean(0)
+        s, d = src - ms, dst - md
+        sig = d.T @ s / len(src)
+        U, sv, Vt = np.linalg.svd(sig)
+        S = np.ones(3)
+        if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+            S[2] = -1
+        R = U @ np.diag(S) @ Vt
+        c = (sv * S).sum() / (s ** 2).sum(1).mean() if scaling else 1.0
+        T = np.eye(4)
+        T[:3, :3] = c * R
+        T[:3, 3] = md - c * R @ ms
+        return T
+
+    src = rng.normal(size=(400, 3))
+    R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    R *= np.sign(np.linalg.det(R))
+    dst = 1.3 * src @ R.T + np.array([0.3, -2.0, 1.0]) + rng.normal(size=src.shape) * 0.01
+    corr = np.arange(400, dtype=np.int32)
+    corr[::9] = -1
+    m = corr >= 0
+    for scaling in (False, True):
+        T = oracle.p2p_compute(src, dst, corr, scaling)
+        assert np.allclose(T, umeyama(src[m], dst[corr[m]], scaling), atol=1e-12)
+    assert np.array_equal(oracle.p2p_compute(src, dst, np.full(400, -1, np.int32)), np.eye(4))  # :51-52
+
+
+def test_point_to_plane_system(oracle):
+    rng = np.random.default_rng(6)
+    src, tgt = rng.normal(size=(300, 3)), rng.normal(size=(350, 3))
+    nrm = rng.normal(size=(350, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    corr = rng.integers(-1, 350, 300).astype(np.int32)
+    T, JTJ, JTr, r2 = oracle.p2plane_compute(src, tgt, nrm, corr)
+    m = corr >= 0
+    vs, vt, nt = src[m], tgt[corr[m]], nrm[corr[m]]
+    r = ((vs - vt) * nt).sum(1)
+    J = np.concatenate([np.cross(vs, nt), nt], axis=1)  # TransformationEstimation.cpp:83-85
+    assert np.allclose(JTJ, J.T @ J, rtol=1e-12) and np.allclose(JTr, J.T @ r, rtol=1e-12, atol=1e-12)
+    assert abs(r2 - (r * r).sum()) < 1e-10
+    x = np.linalg.solve(J.T @ J, -(J.T @ r))  # utility/Eigen.cpp:122
+    assert np.allclose(T, oracle.vec6_to_mat4(x), atol=1e-10)
+    assert abs(oracle.compute_rmse(src, tgt, nrm, corr, 2) - np.sqrt((r * r).mean())) < 1e-12
+    assert abs(oracle.compute_rmse(src, tgt, None, corr, 1) - np.sqrt(((vs - vt) ** 2).sum(1).mean())) < 1e-12
+
+
+def test_voxel_down_sample_vs_numpy(oracle):
+    rng = np.random.default_rng(7)
+    pts = rng.random((4000, 3)) * np.array([2.0, 1.0, 0.5]) - 0.7
+    nrm = rng.normal(size=pts.shape)
+    nrm[5] = np.nan
+    col = rng.random(pts.shape)
+    v = 0.11
+    op, on, oc, ov = oracle.voxel_down_sample(pts, v, nrm, col)
+    vmin = pts.min(0) - v * 0.5  # PointCloud.cpp:279
+    idx = np.floor((pts - vmin) / v).astype(np.int64)
+    keys, inv = np.unique(idx[:, ::-1], axis=0, return_inverse=True)  # sorted by (z, y, x)
+    inv = inv.reshape(-1)
+    assert np.array_equal(ov, keys[:, ::-1].astype(np.int32))
+    cnt = np.bincount(inv)
+    for a, src in ((op, pts), (oc, col)):
+        want = np.stack([np.bincount(inv, src[:, d]) for d in range(3)], 1) / cnt[:, None]
+        assert np.allclose(a, want, rtol=1e-13)
+    good = ~np.isnan(nrm).any(1)
+    want = np.stack([np.bincount(inv[good], nrm[good, d], minlength=len(cnt)) for d in range(3)], 1) / cnt[:, None]
+    assert np.allclose(on, want, rtol=1e-12, atol=1e-15)
+    with pytest.raises(RuntimeError, match="voxel_size <= 0"):
+        oracle.voxel_down_sample(pts, 0.0)
+    with pytest.raises(RuntimeError, match="too small"):
+        oracle.voxel_down_sample(pts * 1e6, 1e-5)
+
+
+def test_estimate_normals_vs_numpy_eigh(oracle):
+    rng = np.random.default_rng(8)
+    pts = rng.random((1500, 3)) * np.array([1.0, 1.0, 0.05])
+    nrm, cnt = oracle.estimate_normals(pts, oracle.KNN, 20, 0.0, want_counts=True)
+    assert np.all(cnt == 20)
+    bad = 0
+    for i in range(0, 1500, 10):
+        d2 = ((pts - pts[i]) ** 2).sum(1)
+        nb = np.argsort(d2, kind="stable")[:20]
+        w, v = np.linalg.eigh(np.cov(pts[nb].T, bias=True))
+        if w[1] - w[0] < 1e-6 * w[2]:
+            continue
+        bad += abs(abs(v[:, 0] @ nrm[i]) - 1.0) > 1e-8
+    assert bad == 0
+    # fewer than 3 neighbours -> (0, 0, 1); flip toward an existing normal (EstimateNormals.cpp:336-349)
+    assert np.all(oracle.estimate_normals(pts, oracle.KNN, 2, 0.0) == [0, 0, 1])
+    prior = rng.normal(size=pts.shape)
+    flipped = oracle.estimate_normals(pts, oracle.KNN, 20, 0.0, normals=prior)
+    assert np.all((flipped * prior).sum(1) >= 0)
+    assert np.allclose(np.abs((flipped * nrm).sum(1)), 1.0, atol=1e-12)
+    assert np.array_equal(oracle.fast_eigen3x3(np.zeros((3, 3))), [0, 0, 0])
+    assert np.array_equal(oracle.fast_eigen3x3(np.diag([3.0, 1.0, 2.0])), [0, 1, 0])
+
+
+def test_config1_point_to_point_100k(oracle):
+    """BASELINE.json config 1: point-to-point ICP, 100k-point synthetic surface with a known rigid transform, CPU."""
+    sc = make_scene(100_000, 100_000, cfg_id=1, L=extent(100_000), theta_deg=0.05)
+    s = sc["spacing"]
+    res = oracle.registration_icp(sc["source"], sc["target"], 3 * s, None, 1, want_log=True)
+    assert res.fitness > 0.999 and res.iterations <= 30
+    assert res.log[-1, 1] < res.log[0, 1]  # rmse went down
+    # recovered pose near the ground truth: point-to-point ICP between two independent samplings slides along the
+    # (locally almost flat) surface, so in-plane translation is only good to about a spacing; height is tight
+    assert np.max(np.abs(res.transformation[:3, 3] - sc["T_true"][:3, 3])) < 1.0 * s
+    assert abs(res.transformation[2, 3] - sc["T_true"][2, 3]) < 0.2 * s
+    assert np.max(np.abs(res.transformation[:3, :3] - sc["T_true"][:3, :3])) < 1e-3
+    # the loop bookkeeping of Registration.cpp:155-166
+    assert len(res.log) == res.iterations + 1
+    with pytest.raises(RuntimeError, match="Invalid max_correspondence_distance"):
+        oracle.registration_icp(sc["source"][:10], sc["target"][:10], 0.0)
+    with pytest.raises(RuntimeError, match="require pre-computed normal vectors"):
+        oracle.registration_icp(sc["source"][:10], sc["target"][:10], 1.0, None, 2, None)
+
+
+def extent(n):
+    from open3d_amd import synthetic
+    return synthetic.extent_for(n)
+
+
+def test_information_matrix(oracle):
+    rng = np.random.default_rng(9)
+    tgt = rng.random((500, 3))
+    src = tgt[:300] + rng.normal(0, 1e-3, (300, 3))
+    G = oracle.information_matrix(src, tgt, 0.05, np.eye(4))
+    corr = oracle.evaluate_registration(src, tgt, 0.05)[0]
+    want = np.zeros((6, 6))
+    for j in corr[corr >= 0]:
+        x, y, z = tgt[j]
+        for row in ([0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]):  # Registration.cpp:326-346
+            want += np.outer(row, row)
+    assert np.allclose(G, want, rtol=1e-12)

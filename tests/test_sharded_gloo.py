@@ -1,0 +1,173 @@
+"""CPU suite: the source-sharded multi-rank ICP driver (open3d_amd/sharded.py) over gloo, world_size 2.
+
+The HIP engine cannot run here (no GPU), so the test injects an engine with the same four methods built on the CPU
+oracle; what is under test is the product's orchestration: contiguous source shards, one all-gather of 32 fp64 sums
+per iteration, rank-ordered summation, identical decisions on every rank, shard-order concatenation of the result.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Stand-in for HipEngine with the semantics of k_icp_search/accumulate + k_icp_solve (device side of the loop)."""
+
+    def setup(self, src, tgt, tgt_normals, max_dist, init, estimation, criteria, n_src_global):
+        import oracle
+        self.orc = oracle
+        self.src = np.array(src, dtype=np.float64)
+        self.tgt, self.nrm = np.asarray(tgt), tgt_normals
+        self.r = max_dist
+        self.T = np.array(init, dtype=np.float64)
+        self.update = np.array(init, dtype=np.float64)
+        self.apply = not oracle.is_identity(init)
+        self.est = estimation.GetTransformationEstimationType()
+        self.scaling = getattr(estimation, "with_scaling_", False)
+        self.crit = criteria
+        self.n_global = n_src_global
+        self.passes = self.iters = 0
+        self.done = False
+        self.fit = self.rmse = 0.0
+        self.corr = np.full(len(self.src), -1, np.int32)
+
+    def pass_into(self, local):
+        if self.done:
+            return
+        if self.apply:
+            self.src = self.orc.transform_points(self.update, self.src)
+        corr, nc, sd2, _, _ = self.orc.correspondences(self.src, self.tgt, self.r)
+        self.corr = corr
+        q = np.zeros(32)
+        m = corr >= 0
+        if nc:
+            if self.est == 2:
+                _, JTJ, JTr, r2 = self.orc.p2plane_compute(self.src, self.tgt, self.nrm, corr)
+                q[:21] = JTJ[np.triu_indices(6)]
+                q[21:27] = JTr
+                q[27] = r2
+            else:
+                s, t = self.src[m], self.tgt[corr[m]]
+                q[0:3], q[3:6] = s.sum(0), t.sum(0)
+                q[6:15] = (t.T @ s).reshape(9)
+                q[15] = (s * s).sum()
+        q[28], q[29] = sd2, nc
+        local.copy_(__import__("torch").from_numpy(q))
+
+    def solve_from(self, all_sums, n_ranks):
+        if self.done:
+            return
+        a = all_sums.numpy().reshape(n_ranks, 32)
+        q = a[0].copy()
+        for r in range(1, n_ranks):
+            q = q + a[r]
+        nc = q[29]
+        fit = nc / self.n_global if nc > 0 else 0.0
+        rmse = np.sqrt(q[28] / nc) if nc > 0 else 0.0
+        pf, pr = self.fit, self.rmse
+        self.fit, self.rmse = fit, rmse
+        p = self.passes
+        self.passes += 1
+        if p >= 1:
+            self.iters = p
+            if abs(pf - fit) < self.crit.relative_fitness_ and abs(pr - rmse) < self.crit.relative_rmse_:
+                self.done = True
+                return
+        if p >= self.crit.max_iteration_:
+            self.done = True
+            return
+        upd = np.eye(4)
+        if nc > 0:
+            if self.est == 2:
+                A = np.zeros((6, 6))
+                A[np.triu_indices(6)] = q[:21]
+                A = A + A.T - np.diag(np.diag(A))
+                upd = self.orc.vec6_to_mat4(self.orc.ldlt_solve(A, -q[21:27]))
+            else:
+                ms, md = q[0:3] / nc, q[3:6] / nc
+                sig = q[6:15].reshape(3, 3) / nc - np.outer(md, ms)
+                U, sv, Vt = np.linalg.svd(sig)
+                S = np.ones(3)
+                if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+                    S[2] = -1
+                R = U @ np.diag(S) @ Vt
+                upd[:3, :3] = R
+                upd[:3, 3] = md - R @ ms
+        self.update = upd
+        self.T = upd @ self.T
+        self.apply = True
+
+    def poll(self):
+        return self.done, self.passes
+
+    def finish(self, want_corr=True):
+        from open3d_amd.pipelines.registration import RegistrationResult
+        res = RegistrationResult(self.T)
+        res.corr_ = self.corr
+        res.fitness_, res.inlier_rmse_, res.iterations_ = self.fit, self.rmse, self.iters
+        return res
+
+
+def _worker(rank, world, port, est_name, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from conftest import make_scene
+    from open3d_amd.pipelines import registration as reg
+    from open3d_amd.sharded import ShardedICP, shard_bounds
+    import oracle
+    oracle.set_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = make_scene(5001, 6000, cfg_id=31)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    lo, hi = shard_bounds(len(sc["source"]), world, rank)
+    est = reg.TransformationEstimationPointToPlane() if est_name == "p2plane" else reg.TransformationEstimationPointToPoint()
+    r = 2 * s if est_name == "p2plane" else 3 * s
+    icp = ShardedICP(OracleEngine(), None, torch.device("cpu"))
+    icp.setup(sc["source"][lo:hi], sc["target"], nrm, r, np.eye(4), est, reg.ICPConvergenceCriteria(), len(sc["source"]))
+    icp.run(check_every=3)
+    res = icp.finish()
+    np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), T=res.transformation_, corr=res.corr_, lo=lo, hi=hi,
+             scalars=np.array([res.fitness_, res.inlier_rmse_, res.iterations_]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("est_name", ["p2plane", "p2p"])
+def test_sharded_icp_two_ranks_matches_single_process(oracle, tmp_path, est_name):
+    import torch.multiprocessing as mp
+    from conftest import make_scene
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + (7 if est_name == "p2p" else 0)
+    mp.spawn(_worker, args=(world, port, est_name, str(tmp_path)), nprocs=world, join=True)
+    sc = make_scene(5001, 6000, cfg_id=31)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    ref = oracle.registration_icp(sc["source"], sc["target"], 2 * s if est_name == "p2plane" else 3 * s, None,
+                                  2 if est_name == "p2plane" else 1, nrm)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    # every rank holds the same transformation and scalars, bit for bit
+    assert np.array_equal(outs[0]["T"], outs[1]["T"]) and np.array_equal(outs[0]["scalars"], outs[1]["scalars"])
+    assert (outs[0]["lo"], outs[0]["hi"], outs[1]["lo"], outs[1]["hi"]) == (0, 2500, 2500, 5001)
+    corr = np.concatenate([o["corr"] for o in outs])  # rank order = ascending source index
+    assert np.array_equal(corr, ref.corr)
+    fit, rmse, iters = outs[0]["scalars"]
+    assert int(iters) == ref.iterations
+    assert abs(fit - ref.fitness) <= 1e-12 and abs(rmse - ref.inlier_rmse) <= 1e-9 * ref.inlier_rmse
+    assert np.max(np.abs(outs[0]["T"] - ref.transformation)) < 1e-8
+
+
+def test_shard_bounds_cover_everything():
+    from open3d_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 10_000_000):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
