@@ -66,8 +66,12 @@ typedef enum { O3D_SEARCH_KNN = 0, O3D_SEARCH_RADIUS = 1, O3D_SEARCH_HYBRID = 2 
 /* ---- context -------------------------------------------------------------- */
 O3D_API int o3d_ctx_create(int device_id, o3d_ctx **out_ctx);
 O3D_API void o3d_ctx_destroy(o3d_ctx *ctx);
-/* Launch everything on an existing hipStream_t (e.g. torch's current stream).  NULL = the context's own stream. */
+/* Launch everything on an existing hipStream_t (e.g. torch's current stream).  The handle is used as given: NULL is
+ * the HIP null stream (torch's default stream), so that work enqueued by the caller on that stream -- an RCCL
+ * all-gather issued through torch.distributed, say -- is ordered with the library's kernels.
+ * o3d_ctx_use_own_stream returns to the private non-blocking stream the context was created with. */
 O3D_API int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream);
+O3D_API int o3d_ctx_use_own_stream(o3d_ctx *ctx);
 O3D_API const char *o3d_last_error(const o3d_ctx *ctx);
 O3D_API const char *o3d_status_string(int status);
 /* 1 when the library was built for and sees a gfx950 device */

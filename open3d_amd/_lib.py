@@ -24,6 +24,7 @@ _SIGNATURES = {
     "o3d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "o3d_ctx_destroy": (None, [C.c_void_p]),
     "o3d_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "o3d_ctx_use_own_stream": (C.c_int, [C.c_void_p]),
     "o3d_last_error": (C.c_char_p, [C.c_void_p]),
     "o3d_status_string": (C.c_char_p, [C.c_int]),
     "o3d_device_count": (C.c_int, []),
@@ -70,6 +71,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: build it with `make -C open3d_amd/csrc` (or __graft_entry__.build()); "
                                "open3d_amd has no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Loading torch
+        # first makes libo3d_amd.so bind to that copy, so device pointers and streams can be shared with torch tensors;
+        # the other order leaves torch unable to initialise its GPU context.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
@@ -128,7 +136,11 @@ class Context:
             raise O3DError(st, msg)
 
     def set_stream(self, stream_handle):
-        self.check(self._lib.o3d_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
+        """Run on the given hipStream_t handle (0 / None = the HIP null stream, torch's default stream)."""
+        self.check(self._lib.o3d_ctx_set_stream(self._h, C.c_void_p(stream_handle or None)))
+
+    def use_own_stream(self):
+        self.check(self._lib.o3d_ctx_use_own_stream(self._h))
 
     def debug_set(self, use_tile_search=False, collect_tile_stats=False):
         """use_tile_search: run the LDS-tile fp32-prefilter search kernel instead of the per-lane fp64 search."""

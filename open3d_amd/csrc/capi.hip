@@ -186,7 +186,15 @@ int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream, which is what torch's default stream is
+  return O3D_OK;
+}
+
+int o3d_ctx_use_own_stream(o3d_ctx *ctx) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = ctx->own_stream;
   return O3D_OK;
 }
 

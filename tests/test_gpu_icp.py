@@ -146,3 +146,78 @@ def test_radius_threshold_is_float_rounded(ctx, oracle):
         assert (d2 < thr) == inside
         got = reg.EvaluateRegistration(geometry.PointCloud(src), geometry.PointCloud(tgt), r, ctx=ctx)
         assert (got.corr_[0] == 0) == inside
+
+
+@pytest.mark.parametrize("est", ["p2p", "p2plane"])
+def test_tile_search_path_matches_oracle(oracle, est):
+    """The LDS-tile fp32-prefilter search (+ fp64 confirmation + exact fixup) must give the same exact result."""
+    geometry, reg = _reg()
+    from open3d_amd import _lib
+    c = _lib.Context(0)
+    c.debug_set(use_tile_search=True, collect_tile_stats=True)
+    try:
+        sc = make_scene(40000, 42000, cfg_id=17)
+        s = sc["spacing"]
+        tgt_n = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+        if est == "p2p":
+            estimation, est_type, r = reg.TransformationEstimationPointToPoint(False), 1, 3 * s
+        else:
+            estimation, est_type, r = reg.TransformationEstimationPointToPlane(), 2, 2 * s
+        got = reg.RegistrationICP(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=tgt_n), r,
+                                  np.eye(4), estimation, reg.ICPConvergenceCriteria(), ctx=c)
+        st = c.tile_stats()
+        assert st["tiled"] > 0, "the tile path did not run"
+        ref = oracle.registration_icp(sc["source"], sc["target"], r, None, est_type, tgt_n)
+        assert got.iterations_ == ref.iterations
+        assert np.array_equal(got.corr_, ref.corr)
+        assert rel_err(got.transformation_, ref.transformation) < TOL
+        assert rel_err(got.inlier_rmse_, ref.inlier_rmse) < TOL
+        # lattice targets with near-tie distances exercise the undecided -> exact fixup route
+        rng = np.random.default_rng(3)
+        g = np.arange(0, 24) * 0.1
+        tgt = np.stack(np.meshgrid(g, g, g[:5], indexing="ij"), -1).reshape(-1, 3)
+        src = tgt[rng.integers(0, len(tgt), 20000)] + rng.choice([0.0, 0.05, -0.05, 1e-9, 0.049999], size=(20000, 3))
+        gotl = reg.EvaluateRegistration(geometry.PointCloud(src), geometry.PointCloud(tgt), 0.1, ctx=c)
+        corr = oracle.evaluate_registration(src, tgt, 0.1)[0]
+        assert np.array_equal(gotl.corr_, corr)
+    finally:
+        c.close()
+
+
+def test_stepwise_sharded_api_on_one_gpu(ctx, oracle):
+    """o3d_icp_pass_to + o3d_icp_solve on torch device tensors (the calls the multi-GPU driver makes), one rank, and a
+    two-shard emulation on one GPU: two contexts, sums concatenated by hand, every context solving from both."""
+    import torch
+    geometry, reg = _reg()
+    from open3d_amd import _lib
+    from open3d_amd.sharded import shard_bounds
+    sc = make_scene(30001, 30000, cfg_id=23)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    ref = oracle.registration_icp(sc["source"], sc["target"], 2 * s, None, 2, nrm, rel_fitness=0, rel_rmse=0, max_iter=6)
+    dev = torch.device("cuda", 0)
+    d_tgt, d_nrm = torch.from_numpy(sc["target"]).to(dev), torch.from_numpy(nrm).to(dev)
+    n = len(sc["source"])
+    ctxs, sess, shards = [], [], []
+    for rnk in range(2):
+        lo, hi = shard_bounds(n, 2, rnk)
+        c = _lib.Context(0)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_src = torch.from_numpy(sc["source"][lo:hi]).to(dev)
+        se = reg.IcpSession(c).setup(d_src, d_tgt, d_nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
+                                     reg.ICPConvergenceCriteria(0, 0, 6), n_src_global=n)
+        ctxs.append(c); sess.append(se); shards.append(d_src)
+    allsums = torch.zeros(64, dtype=torch.float64, device=dev)
+    for _ in range(7):
+        for rnk in range(2):
+            sess[rnk].enqueue_pass_to(allsums[32 * rnk:].data_ptr())
+        for rnk in range(2):
+            sess[rnk].enqueue_solve(allsums.data_ptr(), 2)
+    res = [se.finish() for se in sess]
+    assert np.array_equal(res[0].transformation_, res[1].transformation_)  # bit-identical on both "ranks"
+    assert np.array_equal(np.concatenate([r.corr_ for r in res]), ref.corr)
+    assert res[0].iterations_ == ref.iterations == 6
+    assert rel_err(res[0].transformation_, ref.transformation) < TOL
+    assert rel_err(res[0].fitness_, ref.fitness) < TOL and rel_err(res[0].inlier_rmse_, ref.inlier_rmse) < TOL
+    for c in ctxs:
+        c.close()
