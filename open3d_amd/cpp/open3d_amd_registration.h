@@ -1,0 +1,320 @@
+// open3d_amd_registration.h -- header-only C++ adapter with the reference's own signatures over the C ABI of
+// libo3d_amd.so (include/o3d_icp.h).
+//
+// Mirrors, name for name and default for default:
+//   open3d::pipelines::registration::RegistrationICP / EvaluateRegistration   (pipelines/registration/Registration.h:136-152)
+//   ICPConvergenceCriteria, RegistrationResult                                  (Registration.h:54-76,107-126)
+//   TransformationEstimation{,PointToPoint,PointToPlane}, CorrespondenceSet     (TransformationEstimation.h:43-130)
+//   geometry::PointCloud::VoxelDownSample / EstimateNormals, KDTreeSearchParam* (geometry/PointCloud.h:130,192;
+//                                                                                 geometry/KDTreeSearchParam.h:35-107)
+// Error behaviour follows utility::LogError (utility/Console.h:82-87): a std::runtime_error carrying the reference's
+// "[Open3D ERROR] ..." text.
+//
+// Inside the reference tree, define O3D_AMD_USE_OPEN3D_TYPES before including this header: the adapter then works on
+// open3d::geometry::PointCloud and Eigen types directly.  Stand-alone (no Eigen in the image) it
+// uses the layout-compatible value types below: Vector3d = 3 contiguous doubles, Matrix4d = 16 doubles column-major,
+// Vector2i = 2 ints -- the storage Eigen gives the reference's std::vector<Eigen::Vector3d> (geometry/PointCloud.h:330-334).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "o3d_icp.h"
+
+#ifdef O3D_AMD_USE_OPEN3D_TYPES
+#include "open3d/geometry/KDTreeSearchParam.h"
+#include "open3d/geometry/PointCloud.h"
+#include "open3d/pipelines/registration/Registration.h"
+#include "open3d/pipelines/registration/TransformationEstimation.h"
+#endif
+
+namespace open3d_amd {
+
+// ---- context handling ---------------------------------------------------------------------------------------------
+class Context {
+ public:
+  explicit Context(int device = 0) {
+    const int st = o3d_ctx_create(device, &ctx_);
+    if (st != O3D_OK) throw std::runtime_error(std::string("open3d_amd: ") + o3d_last_error(nullptr));
+  }
+  ~Context() { o3d_ctx_destroy(ctx_); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  o3d_ctx *get() const { return ctx_; }
+  // One context per host thread and device; created on first use.
+  static Context &Default(int device = 0) {
+    thread_local std::unique_ptr<Context> c;
+    if (!c) c.reset(new Context(device));
+    return *c;
+  }
+
+ private:
+  o3d_ctx *ctx_ = nullptr;
+};
+
+inline void Check(o3d_ctx *ctx, int status) {
+  if (status == O3D_OK) return;
+  const char *msg = o3d_last_error(ctx);
+  throw std::runtime_error((msg && *msg) ? msg : o3d_status_string(status));
+}
+
+#ifndef O3D_AMD_USE_OPEN3D_TYPES
+// ---- layout-compatible stand-ins ------------------------------------------------------------------------------------
+struct Vector3d {
+  double v[3];
+  Vector3d() : v{0, 0, 0} {}
+  Vector3d(double x, double y, double z) : v{x, y, z} {}
+  double &operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+};
+struct Vector2i {
+  int v[2];
+  Vector2i() : v{0, 0} {}
+  Vector2i(int a, int b) : v{a, b} {}
+  int operator[](int i) const { return v[i]; }
+  int operator()(int i) const { return v[i]; }
+};
+struct Matrix4d {  // column-major, like Eigen::Matrix4d
+  double m[16];
+  static Matrix4d Identity() {
+    Matrix4d r;
+    for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return r;
+  }
+  double &operator()(int r, int c) { return m[c * 4 + r]; }
+  double operator()(int r, int c) const { return m[c * 4 + r]; }
+  const double *data() const { return m; }
+  double *data() { return m; }
+};
+static_assert(sizeof(Vector3d) == 24 && sizeof(Vector2i) == 8 && sizeof(Matrix4d) == 128, "layout must match Eigen's");
+
+namespace geometry {
+
+class KDTreeSearchParam {  // geometry/KDTreeSearchParam.h:35-57
+ public:
+  enum class SearchType { Knn = 0, Radius = 1, Hybrid = 2 };
+  virtual ~KDTreeSearchParam() {}
+  SearchType GetSearchType() const { return search_type_; }
+
+ protected:
+  explicit KDTreeSearchParam(SearchType t) : search_type_(t) {}
+
+ private:
+  SearchType search_type_;
+};
+class KDTreeSearchParamKNN : public KDTreeSearchParam {  // :62-75
+ public:
+  explicit KDTreeSearchParamKNN(int knn = 30) : KDTreeSearchParam(SearchType::Knn), knn_(knn) {}
+  int knn_;
+};
+class KDTreeSearchParamRadius : public KDTreeSearchParam {  // :77-90
+ public:
+  explicit KDTreeSearchParamRadius(double radius) : KDTreeSearchParam(SearchType::Radius), radius_(radius) {}
+  double radius_;
+};
+class KDTreeSearchParamHybrid : public KDTreeSearchParam {  // :92-107
+ public:
+  KDTreeSearchParamHybrid(double radius, int max_nn) : KDTreeSearchParam(SearchType::Hybrid), radius_(radius), max_nn_(max_nn) {}
+  double radius_;
+  int max_nn_;
+};
+
+class PointCloud {  // the members of geometry/PointCloud.h:330-334 that the ICP path touches
+ public:
+  std::vector<Vector3d> points_, normals_, colors_;
+  bool HasPoints() const { return !points_.empty(); }
+  bool HasNormals() const { return !points_.empty() && normals_.size() == points_.size(); }
+  bool HasColors() const { return !points_.empty() && colors_.size() == points_.size(); }
+  std::shared_ptr<PointCloud> VoxelDownSample(double voxel_size) const;
+  void EstimateNormals(const KDTreeSearchParam &search_param = KDTreeSearchParamKNN(), bool fast_normal_computation = true);
+};
+
+}  // namespace geometry
+namespace o3d_types {
+using geometry::KDTreeSearchParam;
+using geometry::KDTreeSearchParamHybrid;
+using geometry::KDTreeSearchParamKNN;
+using geometry::KDTreeSearchParamRadius;
+using geometry::PointCloud;
+using Mat4 = Matrix4d;
+using Vec2i = Vector2i;
+using Vec3 = Vector3d;
+}  // namespace o3d_types
+#else
+namespace o3d_types {
+using open3d::geometry::KDTreeSearchParam;
+using open3d::geometry::KDTreeSearchParamHybrid;
+using open3d::geometry::KDTreeSearchParamKNN;
+using open3d::geometry::KDTreeSearchParamRadius;
+using open3d::geometry::PointCloud;
+using Mat4 = Eigen::Matrix4d;
+using Vec2i = Eigen::Vector2i;
+using Vec3 = Eigen::Vector3d;
+}  // namespace o3d_types
+#endif
+
+// ---- preprocessing --------------------------------------------------------------------------------------------------
+// PointCloud::VoxelDownSample, geometry/PointCloud.cpp:273-306 (output ordered by voxel index; the reference's order is
+// unordered_map bucket order, i.e. unspecified).
+inline std::shared_ptr<o3d_types::PointCloud> VoxelDownSample(const o3d_types::PointCloud &cloud, double voxel_size,
+                                                               Context &c = Context::Default()) {
+  auto out = std::make_shared<o3d_types::PointCloud>();
+  const int64_t n = (int64_t)cloud.points_.size();
+  const bool hn = cloud.HasNormals(), hc = cloud.HasColors();
+  out->points_.resize(n);
+  if (hn) out->normals_.resize(n);
+  if (hc) out->colors_.resize(n);
+  int64_t m = 0;
+  Check(c.get(), o3d_voxel_down_sample(c.get(), (const double *)cloud.points_.data(), hn ? (const double *)cloud.normals_.data() : nullptr,
+                                       hc ? (const double *)cloud.colors_.data() : nullptr, n, voxel_size, O3D_MEM_HOST,
+                                       (double *)out->points_.data(), hn ? (double *)out->normals_.data() : nullptr,
+                                       hc ? (double *)out->colors_.data() : nullptr, nullptr, &m));
+  out->points_.resize(m);
+  if (hn) out->normals_.resize(m);
+  if (hc) out->colors_.resize(m);
+  return out;
+}
+
+// PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351
+inline void EstimateNormals(o3d_types::PointCloud &cloud, const o3d_types::KDTreeSearchParam &param = o3d_types::KDTreeSearchParamKNN(),
+                            bool fast_normal_computation = true, Context &c = Context::Default()) {
+  if (!fast_normal_computation)
+    throw std::runtime_error("open3d_amd: fast_normal_computation=false (Eigen SelfAdjointEigenSolver) is not on the device path");
+  const bool has = cloud.HasNormals();
+  if (!has) cloud.normals_.resize(cloud.points_.size());
+  int type = (int)param.GetSearchType(), knn = 0;
+  double radius = 0.0;
+  if (type == O3D_SEARCH_KNN) knn = static_cast<const o3d_types::KDTreeSearchParamKNN &>(param).knn_;
+  else if (type == O3D_SEARCH_RADIUS) radius = static_cast<const o3d_types::KDTreeSearchParamRadius &>(param).radius_;
+  else {
+    radius = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).radius_;
+    knn = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).max_nn_;
+  }
+  Check(c.get(), o3d_estimate_normals(c.get(), (const double *)cloud.points_.data(), (int64_t)cloud.points_.size(), type, knn, radius,
+                                      O3D_MEM_HOST, (double *)cloud.normals_.data(), has ? 1 : 0));
+}
+
+#ifndef O3D_AMD_USE_OPEN3D_TYPES
+inline std::shared_ptr<geometry::PointCloud> geometry::PointCloud::VoxelDownSample(double voxel_size) const {
+  return open3d_amd::VoxelDownSample(*this, voxel_size);
+}
+inline void geometry::PointCloud::EstimateNormals(const KDTreeSearchParam &p, bool fast) { open3d_amd::EstimateNormals(*this, p, fast); }
+#endif
+
+// ---- registration -----------------------------------------------------------------------------------------------------
+namespace pipelines {
+namespace registration {
+
+#ifndef O3D_AMD_USE_OPEN3D_TYPES
+typedef std::vector<Vector2i> CorrespondenceSet;  // TransformationEstimation.h:43
+
+enum class TransformationEstimationType { Unspecified = 0, PointToPoint = 1, PointToPlane = 2, ColoredICP = 3 };  // :45-50
+
+class TransformationEstimation {  // :57-80
+ public:
+  virtual ~TransformationEstimation() {}
+  virtual TransformationEstimationType GetTransformationEstimationType() const = 0;
+};
+class TransformationEstimationPointToPoint : public TransformationEstimation {  // :85-107
+ public:
+  explicit TransformationEstimationPointToPoint(bool with_scaling = false) : with_scaling_(with_scaling) {}
+  TransformationEstimationType GetTransformationEstimationType() const override { return TransformationEstimationType::PointToPoint; }
+  bool with_scaling_ = false;
+};
+class TransformationEstimationPointToPlane : public TransformationEstimation {  // :112-130
+ public:
+  TransformationEstimationType GetTransformationEstimationType() const override { return TransformationEstimationType::PointToPlane; }
+};
+
+class ICPConvergenceCriteria {  // Registration.h:54-76
+ public:
+  ICPConvergenceCriteria(double relative_fitness = 1e-6, double relative_rmse = 1e-6, int max_iteration = 30)
+      : relative_fitness_(relative_fitness), relative_rmse_(relative_rmse), max_iteration_(max_iteration) {}
+  double relative_fitness_, relative_rmse_;
+  int max_iteration_;
+};
+
+class RegistrationResult {  // Registration.h:107-126
+ public:
+  explicit RegistrationResult(const Matrix4d &transformation = Matrix4d::Identity())
+      : transformation_(transformation), inlier_rmse_(0.0), fitness_(0.0) {}
+  Matrix4d transformation_;
+  CorrespondenceSet correspondence_set_;
+  double inlier_rmse_, fitness_;
+};
+#else
+using open3d::pipelines::registration::CorrespondenceSet;
+using open3d::pipelines::registration::ICPConvergenceCriteria;
+using open3d::pipelines::registration::RegistrationResult;
+using open3d::pipelines::registration::TransformationEstimation;
+using open3d::pipelines::registration::TransformationEstimationPointToPlane;
+using open3d::pipelines::registration::TransformationEstimationPointToPoint;
+using open3d::pipelines::registration::TransformationEstimationType;
+#endif
+
+namespace detail {
+inline void ExpandCorrespondences(const std::vector<int32_t> &corr, CorrespondenceSet &out) {
+  out.clear();
+  for (size_t i = 0; i < corr.size(); i++)  // ascending source index: the reference's serial order (Registration.cpp:60-68)
+    if (corr[i] >= 0) out.push_back(o3d_types::Vec2i((int)i, corr[i]));
+}
+}  // namespace detail
+
+// True when the estimation runs on the device path (anything else -- ColoredICP, user subclasses -- must keep using the
+// reference's own RegistrationICP; INTEGRATION.md shows the dispatch).
+inline bool IsAccelerated(const TransformationEstimation &e) {
+  const auto t = e.GetTransformationEstimationType();
+  return t == TransformationEstimationType::PointToPoint || t == TransformationEstimationType::PointToPlane;
+}
+
+// EvaluateRegistration, Registration.cpp:118-127
+inline RegistrationResult EvaluateRegistration(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                               double max_correspondence_distance,
+                                               const o3d_types::Mat4 &transformation = o3d_types::Mat4::Identity(),
+                                               Context &c = Context::Default()) {
+  RegistrationResult result(transformation);
+  std::vector<int32_t> corr(source.points_.size());
+  int64_t nc = 0;
+  Check(c.get(), o3d_evaluate_registration(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                           (const double *)target.points_.data(), (int64_t)target.points_.size(),
+                                           max_correspondence_distance, transformation.data(), O3D_MEM_HOST, corr.data(), &nc,
+                                           &result.fitness_, &result.inlier_rmse_));
+  detail::ExpandCorrespondences(corr, result.correspondence_set_);
+  return result;
+}
+
+// RegistrationICP, Registration.cpp:129-168
+inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                          double max_correspondence_distance,
+                                          const o3d_types::Mat4 &init = o3d_types::Mat4::Identity(),
+                                          const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false),
+                                          const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria(),
+                                          Context &c = Context::Default()) {
+  if (!IsAccelerated(estimation))
+    throw std::runtime_error("open3d_amd: only point-to-point and point-to-plane estimation run on the device path");
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  int with_scaling = 0;
+  if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
+  RegistrationResult result(init);
+  std::vector<int32_t> corr(source.points_.size());
+  int64_t nc = 0;
+  int iters = 0;
+  double T[16];
+  Check(c.get(), o3d_registration_icp(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                      (const double *)target.points_.data(),
+                                      target.HasNormals() ? (const double *)target.normals_.data() : nullptr,
+                                      (int64_t)target.points_.size(), max_correspondence_distance, init.data(),
+                                      p2l ? O3D_EST_POINT_TO_PLANE : O3D_EST_POINT_TO_POINT, with_scaling,
+                                      criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, O3D_MEM_HOST, T,
+                                      corr.data(), &nc, &result.fitness_, &result.inlier_rmse_, &iters));
+  for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
+  detail::ExpandCorrespondences(corr, result.correspondence_set_);
+  return result;
+}
+
+}  // namespace registration
+}  // namespace pipelines
+}  // namespace open3d_amd

@@ -1,0 +1,78 @@
+// Drives the C++ adapter (open3d_amd/cpp/open3d_amd_registration.h) the way the reference's callers drive
+// open3d::pipelines::registration: value types in, RegistrationResult out, exceptions for the reference's LogError cases.
+// usage: test_adapter <in.bin> <out.bin>
+//   in : int64 n_src, int64 n_tgt, double radius, double voxel, src[3n], tgt[3m], tgt_normals[3m]
+//   out: p2plane {T[16], fitness, rmse, n_pairs, pairs[2*n_pairs] as double}, evaluate {fitness, rmse, n_pairs},
+//        voxel {m, pts[3m]}, normals(knn 30) {n, nrm[3n]}, error flags {3 doubles}
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "open3d_amd_registration.h"
+
+using namespace open3d_amd;
+namespace reg = open3d_amd::pipelines::registration;
+
+static void put(std::vector<double> &o, double v) { o.push_back(v); }
+
+int main(int argc, char **argv) {
+  if (argc != 3) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 3;
+  int64_t ns, nt;
+  double radius, voxel;
+  if (fread(&ns, 8, 1, f) != 1 || fread(&nt, 8, 1, f) != 1 || fread(&radius, 8, 1, f) != 1 || fread(&voxel, 8, 1, f) != 1) return 4;
+  geometry::PointCloud source, target;
+  source.points_.resize(ns);
+  target.points_.resize(nt);
+  target.normals_.resize(nt);
+  if (fread(source.points_.data(), 24, ns, f) != (size_t)ns || fread(target.points_.data(), 24, nt, f) != (size_t)nt ||
+      fread(target.normals_.data(), 24, nt, f) != (size_t)nt)
+    return 5;
+  fclose(f);
+  std::vector<double> out;
+
+  reg::RegistrationResult r = reg::RegistrationICP(source, target, radius, Matrix4d::Identity(),
+                                                   reg::TransformationEstimationPointToPlane(), reg::ICPConvergenceCriteria());
+  for (int i = 0; i < 16; i++) put(out, r.transformation_.m[i]);
+  put(out, r.fitness_); put(out, r.inlier_rmse_); put(out, (double)r.correspondence_set_.size());
+  for (const auto &c : r.correspondence_set_) { put(out, c[0]); put(out, c[1]); }
+
+  reg::RegistrationResult e = reg::EvaluateRegistration(source, target, radius, r.transformation_);
+  put(out, e.fitness_); put(out, e.inlier_rmse_); put(out, (double)e.correspondence_set_.size());
+
+  auto ds = target.VoxelDownSample(voxel);
+  put(out, (double)ds->points_.size());
+  for (const auto &p : ds->points_) { put(out, p(0)); put(out, p(1)); put(out, p(2)); }
+  if (!ds->HasNormals()) return 6;
+
+  geometry::PointCloud tn;
+  tn.points_ = target.points_;
+  tn.EstimateNormals();
+  put(out, (double)tn.normals_.size());
+  for (const auto &p : tn.normals_) { put(out, p(0)); put(out, p(1)); put(out, p(2)); }
+
+  // the reference's three LogError cases surface as std::runtime_error with its message text
+  double flags[3] = {0, 0, 0};
+  try { reg::RegistrationICP(source, target, 0.0); } catch (const std::runtime_error &x) {
+    flags[0] = std::string(x.what()).find("Invalid max_correspondence_distance") != std::string::npos;
+  }
+  try {
+    geometry::PointCloud bare;
+    bare.points_ = target.points_;
+    reg::RegistrationICP(source, bare, radius, Matrix4d::Identity(), reg::TransformationEstimationPointToPlane());
+  } catch (const std::runtime_error &x) {
+    flags[1] = std::string(x.what()).find("require pre-computed normal vectors") != std::string::npos;
+  }
+  try { target.VoxelDownSample(-1.0); } catch (const std::runtime_error &x) {
+    flags[2] = std::string(x.what()).find("voxel_size <= 0") != std::string::npos;
+  }
+  for (double v : flags) put(out, v);
+
+  f = fopen(argv[2], "wb");
+  if (!f) return 7;
+  fwrite(out.data(), 8, out.size(), f);
+  fclose(f);
+  return 0;
+}

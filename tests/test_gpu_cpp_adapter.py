@@ -1,0 +1,53 @@
+"""GPU test of the header-only C++ adapter (open3d_amd/cpp/open3d_amd_registration.h): a g++-built caller, written
+against the reference's own names and value types, must get what the Python mirror gets through the same C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import make_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_adapter")
+
+
+def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
+    if not os.path.exists(EXE):
+        pytest.fail("tests/cpp/test_adapter is missing: run __graft_entry__.build() (make -C tests/cpp)")
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(6000, 7000, cfg_id=55)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    radius, voxel = 2 * s, 3 * s
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(np.array([len(sc["source"]), len(sc["target"])], np.int64).tobytes())
+        f.write(np.array([radius, voxel], np.float64).tobytes())
+        for a in (sc["source"], sc["target"], nrm):
+            f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    subprocess.run([EXE, fin, fout], check=True, timeout=120)
+    out = np.fromfile(fout, np.float64)
+    T = out[:16].reshape(4, 4).T
+    fit, rmse, npairs = out[16], out[17], int(out[18])
+    pairs = out[19:19 + 2 * npairs].reshape(-1, 2).astype(np.int32)
+    o = 19 + 2 * npairs
+    want = reg.RegistrationICP(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm), radius,
+                               np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx)
+    assert np.array_equal(T, want.transformation_) and fit == want.fitness_ and rmse == want.inlier_rmse_
+    assert np.array_equal(pairs, want.correspondence_set_)
+    ev = reg.EvaluateRegistration(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"]), radius, T, ctx=ctx)
+    assert out[o] == ev.fitness_ and out[o + 1] == ev.inlier_rmse_ and int(out[o + 2]) == len(ev.correspondence_set_)
+    o += 3
+    m = int(out[o]); o += 1
+    ds = geometry.PointCloud(sc["target"], normals=nrm).VoxelDownSample(voxel, ctx=ctx)
+    assert m == len(ds.points_) and np.array_equal(out[o:o + 3 * m].reshape(-1, 3), ds.points_)
+    o += 3 * m
+    n = int(out[o]); o += 1
+    pc = geometry.PointCloud(sc["target"])
+    pc.EstimateNormals(ctx=ctx)
+    assert n == len(pc.points_) and np.array_equal(out[o:o + 3 * n].reshape(-1, 3), pc.normals_)
+    o += 3 * n
+    assert list(out[o:o + 3]) == [1.0, 1.0, 1.0], "reference error messages not surfaced as std::runtime_error"
