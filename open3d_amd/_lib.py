@@ -44,6 +44,7 @@ _SIGNATURES = {
     "o3d_debug_get_source_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
+    "o3d_icp_profile_read2": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
     "o3d_icp_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "o3d_icp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "o3d_icp_finish": (C.c_int, [C.c_void_p, C.c_int, c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp,
@@ -142,9 +143,9 @@ class Context:
     def use_own_stream(self):
         self.check(self._lib.o3d_ctx_use_own_stream(self._h))
 
-    def debug_set(self, use_tile_search=False, collect_tile_stats=False):
-        """use_tile_search: run the LDS-tile fp32-prefilter search kernel instead of the per-lane fp64 search."""
-        self.check(self._lib.o3d_debug_set(self._h, 2 if use_tile_search else 0, int(collect_tile_stats)))
+    def debug_set(self, use_tile_search=True, collect_tile_stats=False):
+        """use_tile_search=False: run the per-lane fp64 search kernel instead of the default fp32-prefilter search."""
+        self.check(self._lib.o3d_debug_set(self._h, 0 if use_tile_search else 1, int(collect_tile_stats)))
 
     def source_perm(self, n_src):
         out = np.empty(n_src, np.uint32)

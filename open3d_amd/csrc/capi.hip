@@ -168,7 +168,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
+                  ctx->corr_out,   ctx->pos_sorted, ctx->pend_mask, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -301,7 +301,7 @@ int o3d_icp_step(o3d_ctx *ctx) {
 int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   ctx->force_generic = force_generic_pass & 1;
-  ctx->use_tile = (force_generic_pass & 2) ? 1 : 0;
+  ctx->use_tile = force_generic_pass ? 0 : 1;
   ctx->tile_stats = collect_tile_stats;
   return O3D_OK;
 }
@@ -331,17 +331,30 @@ int o3d_icp_profile(o3d_ctx *ctx, int enable) {
   return O3D_OK;
 }
 
+int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count);
 int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count) {
+  double ms2[2];
+  const int st = o3d_icp_profile_read2(ctx, ms2, out_count);
+  if (st == O3D_OK && out_mean_ms) *out_mean_ms = ms2[0] + ms2[1];
+  return st;
+}
+
+int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double tot = 0;
+  double tot[2] = {0, 0};
   for (int i = 0; i < ctx->prof_n; i++) {
     float ms = 0;
-    O3D_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
-    tot += ms;
+    O3D_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[3 * i], ctx->prof_ev[3 * i + 1]));
+    tot[0] += ms;
+    O3D_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[3 * i + 1], ctx->prof_ev[3 * i + 2]));
+    tot[1] += ms;
   }
-  if (out_mean_ms) *out_mean_ms = ctx->prof_n ? tot / ctx->prof_n : 0.0;
+  if (out_mean_ms) {
+    out_mean_ms[0] = ctx->prof_n ? tot[0] / ctx->prof_n : 0.0;
+    out_mean_ms[1] = ctx->prof_n ? tot[1] / ctx->prof_n : 0.0;
+  }
   if (out_count) *out_count = ctx->prof_n;
   ctx->prof_n = 0;
   return O3D_OK;

@@ -212,6 +212,7 @@ struct PassArgs {
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, -1 none, -2 left to k_icp_fixup, -3 unconfirmed candidate at pos
   uint32_t *pos;   // per processing position: position of the match in tgt_sorted
+  unsigned long long *pend;  // one bit per processing position: left to k_icp_fixup (word w covers positions 64w..64w+63)
   double *partials;
   double thr;
 };
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
         if (d2 < a.thr) {
           a.corr[i] = (int32_t)b.idx;
         } else {
-          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the tile pass's error bound; stay exact regardless
+          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the fp32 error bound; stay exact regardless
+          atomicOr(&a.pend[i >> 6], 1ull << (i & 63));
           continue;
         }
       }
@@ -308,77 +310,80 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Tile pass (the fast path).  Every 16-lane quarter of a wavefront (a "group") takes 16 consecutive source points of
-// the Morton order -- a compact patch of ~2x2 cells -- and
-//   1. finds the patch's bounding box of cells (group min/max by DPP shuffles), widened by one cell on every side;
-//   2. stages every target point of that box ONCE into the group's LDS slice as fp32 coordinates relative to the box
-//      origin (w = position in tgt_sorted).  The box is a set of x-runs, one per (y, z) row; their lengths are
-//      prefix-summed in the group, and each lane fetches up to 8 staged items whose row it finds by a 6-step binary
-//      search of the prefix in LDS -- so all candidate loads of the tile are in flight together;
-//   3. lets each lane test every staged candidate of its group in a wave-uniform loop (ds_read_b128 serves one
-//      address per 16-lane group per cycle: the four groups' broadcasts cost nothing extra), tracking the best and
-//      second-best fp32 distance: 11 full-rate VALU instructions per candidate, no divergence, no per-lane gathers;
-//   4. confirms the winner in fp64 from tgt_sorted (arithmetic identical to the generic path).  A lane whose fp32
-//      result is not decisive -- runner-up within the fp32 error bound, winner within the bound of the acceptance
-//      threshold, query outside the grid, box too large -- runs the exact per-lane fp64 search, so the result is always
-//      the exact argmin over (d2, index).
-// fp32 error budget (h = cell size, box <= 12 cells per axis): every staged coordinate and query coordinate is within
-// 2e-6 h of its exact box-relative value, so |d2_fp32 - d2| <= 1.2e-5 h^2 for any candidate that can matter
-// (d2 <= ~h^2).  kTileErr = 3e-5 (x h^2) is the bound e: decisive means second - best > 2e and |best - thr| > e.
-constexpr int kG = 8;                   // lanes per group
-constexpr int kNG = O3D_WAVE / kG;      // groups per wave
-constexpr int kGroupCap = 96;           // staged candidates per group (x 16 B of LDS)
-constexpr int kRowsPerLane = 4;
-constexpr int kGroupRows = kG * kRowsPerLane;  // (y, z) rows of the widened box
-constexpr int kItemsPerLane = kGroupCap / kG;  // staged items fetched by one lane
-constexpr int kSlice = kGroupCap + 1;   // float4 stride between group slices: rotates each group by 4 LDS banks
-constexpr int kTileMaxX = 10;           // cells per axis of the widened box
-constexpr float kTileErr = 3e-5f;
+// fp32 prefilter search (the fast path).  Same 3x3x3 cell block per lane as the generic search, but
+//   * candidates are read as 16-byte fp32 records (tgt_local: position relative to the candidate's own cell origin,
+//     w = padded x cell index) and compared in fp32 relative to the QUERY's cell origin -- 11 full-rate VALU
+//     instructions and half the bytes per candidate instead of an fp64 evaluation;
+//   * the centre cell is scanned first; the up-to-ten other runs that survive the face-distance pruning are written to
+//     a per-lane list in LDS and walked by ONE flattened loop, so a wavefront iterates max-over-lanes of the per-lane
+//     work instead of the sum over ten divergent scan sites;
+//   * the lane keeps the best and the second-best fp32 distance.  The winner is handed to k_icp_accumulate, which
+//     confirms it in fp64 with the arithmetic of the exact search.  When the fp32 result is not decisive -- runner-up
+//     within the fp32 error bound of the winner, winner within the bound of the acceptance threshold, query outside
+//     the grid -- the point is left to k_icp_fixup's exact fp64 search.  The result is therefore always the exact
+//     argmin over (d2, index).
+// fp32 error budget (h = cell size): candidate and query coordinates are formed relative to the query's cell origin with
+// magnitude <= 2h; each is within 4e-7 h of its exact value, so |d2_fp32 - d2| <= 1.6e-6 h^2 for every candidate of
+// the block (d2 <= 12 h^2 is irrelevant beyond ~h^2).  kF32Err = 4e-6 (x h^2) is used as the bound e: "decisive" means
+// second - best > 2e and |best - thr| > e; runs are pruned only when their face distance exceeds best + 4e.
+constexpr float kF32Err = 4e-6f;
+constexpr int kMaxRuns = 10;  // left cell, right cell, eight neighbouring rows
 
-struct WaveLds {
-  float4 cand[kNG * kSlice];
-  uint32_t roff[kNG][kGroupRows];
-  uint32_t rs[kNG][kGroupRows];
+// Four consecutive cell-table entries in one 16-byte load (the table is only 4-byte aligned at an arbitrary cell:
+// gfx950 global loads take dword-aligned dwordx4 addresses).  One L1 access instead of four.
+struct __attribute__((packed, aligned(4))) CellQuad {
+  uint32_t v[4];
 };
 
-__device__ __forceinline__ int grp_min_i(int v) {
+struct F32State {
+  float best, second;
+  uint32_t bpos;
+};
+
+// Up to four candidates of tgt_local[j, e): slots past the end are neutralised (d2 = +inf), so that `second` never
+// sees a duplicate of the winner.
+__device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_t j, uint32_t e, float qx, float qy, float qz,
+                                          int cxp, float oy, float oz, float hf, F32State &st) {
+  const uint32_t last = e - 1;
+  const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+  const float4 c0 = tl[j], c1 = tl[j1], c2 = tl[j2], c3 = tl[j3];
+  const float4 c[4] = {c0, c1, c2, c3};
+  const uint32_t jj[4] = {j, j1, j2, j3};
 #pragma unroll
-  for (int d = kG / 2; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, O3D_WAVE));
-  return v;
-}
-__device__ __forceinline__ int grp_max_i(int v) {
-#pragma unroll
-  for (int d = kG / 2; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, O3D_WAVE));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, O3D_WAVE));
-  return v;
+  for (int u = 0; u < 4; u++) {
+    const float dx = qx - (c[u].x + (float)(__float_as_int(c[u].w) - cxp) * hf);
+    const float dy = qy - (c[u].y + oy);
+    const float dz = qz - (c[u].z + oz);
+    float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    if (u > 0 && j + u > last) d2 = INFINITY;
+    st.second = fminf(st.second, fmaxf(d2, st.best));
+    st.bpos = d2 < st.best ? jj[u] : st.bpos;
+    st.best = fminf(st.best, d2);
+  }
 }
 
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_tile(PassArgs a, GridParams gp) {
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridParams gp) {
   if (a.st->done) return;
-  __shared__ WaveLds lds[O3D_BLOCK / O3D_WAVE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane / kG, lg = lane % kG;
-  float4 *my = lds[wave].cand + grp * kSlice;
-  uint32_t *my_roff = lds[wave].roff[grp];
-  uint32_t *my_rs = lds[wave].rs[grp];
+  __shared__ uint32_t run_s[kMaxRuns][O3D_BLOCK];
+  __shared__ uint32_t run_e[kMaxRuns][O3D_BLOCK];
+  __shared__ unsigned char run_code[kMaxRuns][O3D_BLOCK];  // (dy + 1) + 3 * (dz + 1)
+  const int tid = threadIdx.x;
   const int apply = a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-
   const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
   const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t beg = (int64_t)chunk * per;
   const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
   const float hf = (float)gp.h;
-  const float err = kTileErr * hf * hf;
+  const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
+  const float margin = 1e-5f * hf;
+  const float4 *__restrict__ tl = a.tgt_local;
+  const uint32_t *__restrict__ cs = a.cell_start;
 
-  for (int64_t base = beg + wave * O3D_WAVE; base < end; base += O3D_BLOCK) {  // wave-uniform trip count
-    const int64_t i = base + lane;
+  for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
+    const int64_t i = base + tid;
     const bool valid = i < end;
     double x = 0, y = 0, z = 0;
     if (valid) {
@@ -392,165 +397,129 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_tile(PassArgs a, GridP
     const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
     const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
     const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
-    bool exact = valid && !inside;  // lanes that need the per-lane fp64 search
-    int32_t verdict = O3D_CORR_NONE;
-
-    // 1. widened bounding box of the group's inside lanes (uniform within the group)
-    const int big = 1 << 30;
-    const int x0 = grp_min_i(inside ? cx : big), x1 = grp_max_i(inside ? cx : -big);
-    const int y0 = grp_min_i(inside ? cy : big), y1 = grp_max_i(inside ? cy : -big);
-    const int z0 = grp_min_i(inside ? cz : big), z1 = grp_max_i(inside ? cz : -big);
-    bool tile = x1 >= x0;  // at least one inside lane
-    // padded x cell indices of every row's run [px0, px1] = unpadded x0-1 .. x1+1 (the pads at -1 and nx are empty cells)
-    const int px0 = x0, px1 = x1 + 2;
-    const int by0 = max(y0 - 1, 0), by1 = min(y1 + 1, gp.ny - 1);
-    const int bz0 = max(z0 - 1, 0), bz1 = min(z1 + 1, gp.nz - 1);
-    const int nby = by1 - by0 + 1, nbz = bz1 - bz0 + 1;
-    const int nrows = nby * nbz;
-    tile = tile && (px1 - px0 + 1) <= kTileMaxX && nby <= kTileMaxX && nbz <= kTileMaxX && nrows <= kGroupRows;
-    const uint32_t magic = tile ? (65536u / (uint32_t)nby + 1u) : 0u;  // floor(r / nby) = (r * magic) >> 16 for r < 64
-
-    // 2a. lane owns rows 4*lg .. 4*lg+3: run starts and lengths from the dense cell table, prefix over the group
-    uint32_t rs4[kRowsPerLane], rl4[kRowsPerLane];
+    int32_t verdict = valid && !inside ? O3D_CORR_PENDING : O3D_CORR_NONE;
+    F32State st;
+    st.best = INFINITY; st.second = INFINITY; st.bpos = 0;
+    int nruns = 0;
+    float qx = 0, qy = 0, qz = 0;
+    const int cxp = cx + 1;  // padded x index of the query's cell
+    if (inside) {
+      // position inside the query's cell (fp64, then rounded once)
+      qx = (float)((x - gp.gmin[0]) - (double)cx * gp.h);
+      qy = (float)((y - gp.gmin[1]) - (double)cy * gp.h);
+      qz = (float)((z - gp.gmin[2]) - (double)cz * gp.h);
+      const uint32_t rowc = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx;
+      const CellQuad qc = *reinterpret_cast<const CellQuad *>(cs + rowc);
+      const uint32_t s0 = qc.v[0], s1 = qc.v[1], s2 = qc.v[2], s3 = qc.v[3];
+      // the eight neighbouring rows, slot r = (dy + 1) + 3 * (dz + 1) (rows outside the grid read a clamped, valid
+      // address); fully unrolled with static slots so that the table stays in registers
+      uint32_t q0[9], q1[9], q2[9], q3[9];
 #pragma unroll
-    for (int q = 0; q < kRowsPerLane; q++) {
-      rs4[q] = 0; rl4[q] = 0;
-      const int r = kRowsPerLane * lg + q;
-      if (tile && r < nrows) {
-        const int zq = (int)(((uint32_t)r * magic) >> 16);
-        const int yy = by0 + (r - zq * nby), zz = bz0 + zq;
-        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-        rs4[q] = a.cell_start[row + (uint32_t)px0];
-        rl4[q] = a.cell_start[row + (uint32_t)px1 + 1u] - rs4[q];
+      for (int r = 0; r < 9; r++) {
+        if (r == 4) continue;
+        const int dy = r % 3 - 1, dz = r / 3 - 1;
+        const int zz = min(max(cz + dz, 0), gp.nz - 1), yy = min(max(cy + dy, 0), gp.ny - 1);
+        const uint32_t rr = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp + (uint32_t)cx;
+        const CellQuad t4 = *reinterpret_cast<const CellQuad *>(cs + rr);
+        q0[r] = t4.v[0]; q1[r] = t4.v[1]; q2[r] = t4.v[2]; q3[r] = t4.v[3];
       }
-    }
-    const uint32_t lane_tot = rl4[0] + rl4[1] + rl4[2] + rl4[3];
-    uint32_t inc = lane_tot;
+      // centre cell first
+      for (uint32_t j = s1; j < s2; j += 4) scan4_f32(tl, j, s2, qx, qy, qz, cxp, 0.f, 0.f, hf, st);
+      // conservative squared face distances (fp32, shrunk by a margin that dominates the rounding)
+      float t;
+      t = fmaxf(qx - margin, 0.f); const float axm = t * t;
+      t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
+      t = fmaxf(qy - margin, 0.f); const float aym = t * t;
+      t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
+      t = fmaxf(qz - margin, 0.f); const float azm = t * t;
+      t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
+      const float reach = fminf(st.best, thrf + err) + 4.0f * err;
+      if (axm <= reach && s0 < s1) { run_s[nruns][tid] = s0; run_e[nruns][tid] = s1; run_code[nruns][tid] = 4; nruns++; }
+      if (axp <= reach && s2 < s3) { run_s[nruns][tid] = s2; run_e[nruns][tid] = s3; run_code[nruns][tid] = 4; nruns++; }
 #pragma unroll
-    for (int d = 1; d < kG; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d, kG);
-      if (lg >= d) inc += o;
-    }
-    const int tot = (int)__shfl(inc, kG - 1, kG);
-    tile = tile && tot <= kGroupCap;
-    {
-      const uint32_t never = 0x7fffffffu;  // rows past the box (or an untiled group): never selected by the search
-      uint32_t o = inc - lane_tot;
-      uint4 ro;
-      ro.x = (tile && kRowsPerLane * lg + 0 < nrows) ? o : never; o += rl4[0];
-      ro.y = (tile && kRowsPerLane * lg + 1 < nrows) ? o : never; o += rl4[1];
-      ro.z = (tile && kRowsPerLane * lg + 2 < nrows) ? o : never; o += rl4[2];
-      ro.w = (tile && kRowsPerLane * lg + 3 < nrows) ? o : never;
-      *reinterpret_cast<uint4 *>(my_roff + kRowsPerLane * lg) = ro;
-      *reinterpret_cast<uint4 *>(my_rs + kRowsPerLane * lg) = make_uint4(rs4[0], rs4[1], rs4[2], rs4[3]);
-    }
-    const int gtot = tile ? tot : 0;
-    const int max_tot = (wave_max_i(gtot) + 3) & ~3;  // wave-uniform scan length, multiple of the unroll factor
-    __builtin_amdgcn_wave_barrier();
-
-    // 2b. stage: item t of the group -> (row, k) by binary search of the row prefix in LDS; the candidate loads of
-    //     half a tile are in flight together
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      constexpr int kH = kItemsPerLane / 2;
-      float4 it[kH];
-      uint32_t itpos[kH];
-#pragma unroll
-      for (int m = 0; m < kH; m++) {
-        const int t = lg + kG * (half * kH + m);
-        uint32_t rho = 0;
-#pragma unroll
-        for (int step = kGroupRows / 2; step >= 1; step >>= 1)
-          if (my_roff[rho + step] <= (uint32_t)t) rho += step;
-        itpos[m] = my_rs[rho] + ((uint32_t)t - my_roff[rho]);
-        const int zq = (int)((rho * magic) >> 16);
-        it[m].y = (float)((int)rho - zq * nby) * hf;  // row offsets inside the box
-        it[m].z = (float)zq * hf;
-        it[m].x = 0.f; it[m].w = 0.f;
-      }
-#pragma unroll
-      for (int m = 0; m < kH; m++) {
-        const int t = lg + kG * (half * kH + m);
-        if (t < gtot) {
-          const float4 c = a.tgt_local[itpos[m]];
-          it[m].x = c.x + (float)(__float_as_int(c.w) - px0) * hf;
-          it[m].y += c.y;
-          it[m].z += c.z;
-          it[m].w = __uint_as_float(itpos[m]);
+      for (int r = 0; r < 9; r++) {
+        if (r == 4) continue;
+        const int dy = r % 3 - 1, dz = r / 3 - 1;
+        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
+        const int zz = cz + dz, yy = cy + dy;
+        if (byz <= reach && zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny) {
+          const uint32_t s = (axm + byz <= reach) ? q0[r] : q1[r];  // corner reach: widen the run to the left cell
+          const uint32_t e = (axp + byz <= reach) ? q3[r] : q2[r];  // ... and to the right cell
+          if (s < e) {
+            run_s[nruns][tid] = s; run_e[nruns][tid] = e;
+            run_code[nruns][tid] = (unsigned char)r;
+            nruns++;
+          }
         }
       }
-#pragma unroll
-      for (int m = 0; m < kH; m++) {
-        const int t = lg + kG * (half * kH + m);
-        if (t < gtot) my[t] = it[m];
-        else if (t < max_tot) my[t] = make_float4(1e18f, 1e18f, 1e18f, 0.f);  // padding: never best nor runner-up
+    }
+    // flattened walk over the lane's surviving runs (LDS columns are lane-private: no barrier needed)
+    {
+      int li = 0;
+      uint32_t j = 0, e = 0;
+      float oy = 0.f, oz = 0.f;
+      bool active = li < nruns;
+      if (active) {
+        j = run_s[0][tid]; e = run_e[0][tid];
+        const int code = run_code[0][tid];
+        oy = (float)(code % 3 - 1) * hf; oz = (float)(code / 3 - 1) * hf;
+      }
+      while (__any(active)) {
+        if (active) {
+          scan4_f32(tl, j, e, qx, qy, qz, cxp, oy, oz, hf, st);
+          j += 4;
+          if (j >= e) {
+            li++;
+            active = li < nruns;
+            if (active) {
+              j = run_s[li][tid]; e = run_e[li][tid];
+              const int code = run_code[li][tid];
+              oy = (float)(code % 3 - 1) * hf; oz = (float)(code / 3 - 1) * hf;
+            }
+          }
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-
-    // 3. wave-uniform scan of the staged candidates (each group reads its own slice)
-    const float qx = (float)((x - gp.gmin[0]) - (double)(px0 - 1) * gp.h);
-    const float qy = (float)((y - gp.gmin[1]) - (double)by0 * gp.h);
-    const float qz = (float)((z - gp.gmin[2]) - (double)bz0 * gp.h);
-    float best = INFINITY, second = INFINITY;
-    uint32_t bpos = 0;
-    for (int j = 0; j < max_tot; j += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float4 c = my[j + u];
-        const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        second = fminf(second, fmaxf(d2, best));
-        bpos = d2 < best ? __float_as_uint(c.w) : bpos;
-        best = fminf(best, d2);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // 4. decisive?  then the winner goes to k_icp_accumulate for fp64 confirmation; otherwise to the exact search
     if (inside) {
-      if (!tile) {
-        exact = true;
-      } else {
-        const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
-        const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
-        if (best <= thrf + err && (near_tie || near_thr)) exact = true;
-        else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
-      }
+      const bool near_tie = (st.second - st.best) <= 2.0f * err;  // inf - inf = NaN -> false
+      const bool near_thr = fabsf(st.best - thrf) <= err + 1e-6f * thrf;
+      if (st.best <= thrf + err && (near_tie || near_thr)) verdict = O3D_CORR_PENDING;
+      else if (st.best < thrf) verdict = O3D_CORR_CANDIDATE;
     }
     if (a.stats) {
-      const unsigned long long ne = __popcll(__ballot(exact)), nv = __popcll(__ballot(valid));
-      const unsigned long long nt = __popcll(__ballot(tile && lg == 0));
-      unsigned long long csum = (lg == 0) ? (unsigned long long)gtot : 0ull;
+      const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
+      unsigned long long rsum = (unsigned long long)nruns;
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) csum += __shfl_xor(csum, d, O3D_WAVE);
-      if (lane == 0) {
-        atomicAdd(&g_tile_stats[0], (unsigned long long)kNG);
-        atomicAdd(&g_tile_stats[1], nt);
-        atomicAdd(&g_tile_stats[2], csum);
-        atomicAdd(&g_tile_stats[3], ne);
-        atomicAdd(&g_tile_stats[4], (unsigned long long)max_tot);
+      for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d, O3D_WAVE);
+      if ((tid & 63) == 0) {
+        atomicAdd(&g_tile_stats[0], 1ull);
+        atomicAdd(&g_tile_stats[1], 1ull);
+        atomicAdd(&g_tile_stats[2], rsum);
+        atomicAdd(&g_tile_stats[3], np);
         atomicAdd(&g_tile_stats[5], nv);
       }
     }
     if (valid) {
-      a.corr[i] = exact ? O3D_CORR_PENDING : verdict;
-      a.pos[i] = bpos;
+      a.corr[i] = verdict;
+      a.pos[i] = st.bpos;
     }
+    const unsigned long long pm = __ballot(verdict == O3D_CORR_PENDING);
+    if ((tid & 63) == 0 && base + (tid & ~63) < end) a.pend[(base + (tid & ~63)) >> 6] = pm;
   }
 }
 
-// Exact per-lane fp64 search for the points the tile pass left undecided (corr == -2).  Each workgroup walks a
+// Exact per-lane fp64 search for the points the fp32 prefilter search left undecided (corr == -2).  Each workgroup walks a
 // contiguous slice of the source in 4096-point tiles, compacts the pending indices of a tile into LDS in index order
 // (block prefix scan: deterministic), and processes the compact list densely.  Its sums go to partial rows of their
 // own behind the tile pass's rows.
-constexpr int kFixTile = 4096;
+constexpr int kFixTile = 4096;   // points per scan step: 64 mask words, one per lane of the first wave
+constexpr int kFixList = 8192;   // pending indices gathered in LDS before they are searched
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams gp, int row0) {
   if (a.st->done) return;
   __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
-  __shared__ uint32_t list[kFixTile];
-  __shared__ uint32_t wtot[O3D_BLOCK / O3D_WAVE];
+  __shared__ uint32_t list[kFixList];  // offsets from the block's first point
+  __shared__ uint32_t s_total;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
   double acc[30];
@@ -559,42 +528,46 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams 
   const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + kFixTile - 1) / kFixTile * kFixTile;
   const int64_t beg = (int64_t)blockIdx.x * per;
   const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-  for (int64_t t0 = beg; t0 < end; t0 += kFixTile) {
-    // thread owns 16 consecutive entries (four int4 loads would need alignment: t0 and 16*tid are multiples of 16)
-    const int64_t e0 = t0 + 16 * (int64_t)threadIdx.x;
-    uint32_t mask = 0;
+  uint32_t fill = 0;  // entries in the list (block-uniform: every thread tracks it through s_total)
+  for (int64_t t0 = beg; t0 < end || fill > 0; t0 += kFixTile) {
+    const bool scanning = t0 < end;
+    if (scanning) {
+      // the first wave reads 64 pending-mask words (one per lane) and appends the set bits in index order
+      if (wave == 0) {
+        unsigned long long mask = 0;
+        if (t0 + 64 * (int64_t)lane < end) mask = a.pend[(t0 >> 6) + lane];
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        uint32_t inc = cnt;
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-      if (e0 + k < end && a.corr[e0 + k] == -2) mask |= 1u << k;
-    const uint32_t cnt = __popc(mask);
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int d = 1; d < O3D_WAVE; d <<= 1) {
-      const uint32_t o = __shfl_up(inc, d, O3D_WAVE);
-      if (lane >= d) inc += o;
+        for (int d = 1; d < O3D_WAVE; d <<= 1) {
+          const uint32_t o = __shfl_up(inc, d, O3D_WAVE);
+          if (lane >= d) inc += o;
+        }
+        uint32_t o = fill + inc - cnt;
+        const uint32_t off0 = (uint32_t)(t0 - beg) + 64u * (uint32_t)lane;
+        for (unsigned long long m = mask; m; m &= m - 1) list[o++] = off0 + (uint32_t)(__ffsll((long long)m) - 1);
+        if (lane == 63) s_total = fill + inc;
+      }
+      __syncthreads();
+      fill = s_total;
     }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int q = 0; q < O3D_BLOCK / O3D_WAVE; q++) {
-      if (q < wave) wbase += wtot[q];
-      total += wtot[q];
-    }
-    uint32_t o = wbase + inc - cnt;
-    for (uint32_t m = mask; m; m &= m - 1) list[o++] = (uint32_t)(e0 - t0) + (uint32_t)(__ffs(m) - 1);
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < total; q += O3D_BLOCK) {
-      const int64_t i = t0 + list[q];
-      const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
-      Best b;
-      b.d2 = a.thr; b.idx = -1; b.pos = 0;
-      nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
-      a.corr[i] = (int32_t)b.idx;
-      a.pos[i] = b.pos;
-      if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], a.nrm, cx0, cy0, cz0);
+    // search the gathered points once the list could overflow on the next step, or at the end of the slice
+    const bool flush = fill > 0 && (!scanning || t0 + kFixTile >= end || fill + kFixTile > kFixList);
+    if (flush) {
+      for (uint32_t q = threadIdx.x; q < fill; q += O3D_BLOCK) {
+        const int64_t i = beg + list[q];
+        const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
+        Best b;
+        b.d2 = a.thr; b.idx = -1; b.pos = 0;
+        nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
+        a.corr[i] = (int32_t)b.idx;
+        a.pos[i] = b.pos;
+        if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], a.nrm, cx0, cy0, cz0);
+      }
+      fill = 0;
     }
     __syncthreads();
+    if (!scanning) break;
   }
   block_reduce_store(acc, red, a.partials, (unsigned)(row0 + blockIdx.x));
 }
@@ -913,11 +886,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__res
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const int g = ctx->pass_grid;
-  const bool prof = ctx->prof_on && ctx->prof_n < 512;
-  if (prof) {
-    for (int k = 0; k < 2; k++)
-      if (!ctx->prof_ev[2 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[2 * ctx->prof_n + k]));
-    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], ctx->stream));
+  const bool prof = ctx->prof_on && ctx->prof_n < 340;
+  if (prof) {  // three events per pass: before the search, after it, after accumulate (+ fixup)
+    for (int k = 0; k < 3; k++)
+      if (!ctx->prof_ev[3 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[3 * ctx->prof_n + k]));
+    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n], ctx->stream));
   }
   PassArgs pa;
   pa.stats = ctx->tile_stats;
@@ -926,11 +899,13 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
   pa.pos = ctx->pos_sorted;
+  pa.pend = ctx->pend_mask;
   const int gf = O3D_FIX_GRID;
   const int nparts = g + gf;
   const bool tiled = ctx->tile_ok && ctx->use_tile && !ctx->force_generic;
-  if (tiled) hipLaunchKernelGGL(k_icp_search_tile, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  if (tiled) hipLaunchKernelGGL(k_icp_search_f32, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
   else hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
   if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
   else hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
   if (tiled) {
@@ -940,7 +915,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)g * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {
-    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], ctx->stream));
+    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 2], ctx->stream));
     ctx->prof_n++;
   }
   if (fuse_solve)

@@ -67,8 +67,8 @@ struct o3d_ctx {
   double *nrm_sorted = nullptr;   // 3 doubles per sorted target point (nullable)
   float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
   size_t cap_local = 0;
-  int tile_ok = 0;                // fp32 wave-tile prefilter usable on this grid
-  int use_tile = 0;               // run k_icp_search_tile instead of k_icp_search when tile_ok
+  int tile_ok = 0;                // fp32 prefilter usable on this grid (cell origins exact to fp32 resolution)
+  int use_tile = 1;               // fp32 prefilter search (k_icp_search_f32) when tile_ok; 0: per-lane fp64 search
   int tile_stats = 0;             // collect g_tile_stats
   int force_generic = 0;          // tests: run the generic per-lane fp64 pass instead of the wave-tile pass
   uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
@@ -81,6 +81,7 @@ struct o3d_ctx {
   int32_t *corr_sorted = nullptr;  // per processing position
   int32_t *corr_out = nullptr;     // caller's order (device staging)
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
+  unsigned long long *pend_mask = nullptr;  // one bit per processing position: left to k_icp_fixup
   size_t cap_src = 0;
 
   // loop

@@ -170,6 +170,14 @@ class IcpSession:
         c.check(c._lib.o3d_icp_profile_read(c.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_read2(self):
+        """((search ms, accumulate ms), passes recorded): mean kernel durations from HIP events on the launch stream."""
+        c = self.ctx
+        ms = np.zeros(2)
+        n = C.c_int()
+        c.check(c._lib.o3d_icp_profile_read2(c.handle, ms.ctypes.data_as(_lib.c_dp), C.byref(n)))
+        return (float(ms[0]), float(ms[1])), n.value
+
     def local_sums_ptr(self):
         return self.ctx._lib.o3d_icp_local_sums(self.ctx.handle)
 

@@ -5,7 +5,8 @@ export TMPDIR=/tmp
 R=$PWD
 TAG=$1
 run() { # name, counters
-  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $R/gpurun_out/pmc_${TAG}_$1 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$1.log 2>&1
+  EXTRA=${BENCH_ARGS:-}
+  timeout -s KILL 120 rocprofv3 --pmc $2 --output-format csv -d $R/gpurun_out/pmc_${TAG}_$1 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $EXTRA > $R/gpurun_out/pmc_${TAG}_$1.log 2>&1
 }
 run sq "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"
 run tcp "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCC_HIT_sum TCC_MISS_sum"

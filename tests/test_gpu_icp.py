@@ -149,12 +149,15 @@ def test_radius_threshold_is_float_rounded(ctx, oracle):
 
 
 @pytest.mark.parametrize("est", ["p2p", "p2plane"])
-def test_tile_search_path_matches_oracle(oracle, est):
-    """The LDS-tile fp32-prefilter search (+ fp64 confirmation + exact fixup) must give the same exact result."""
+@pytest.mark.parametrize("f32", [True, False])
+def test_both_search_kernels_match_oracle(oracle, est, f32):
+    """fp32-prefilter search (+ fp64 confirmation + exact fixup; the default) and the per-lane fp64 search kernel must
+    both give the exact result."""
     geometry, reg = _reg()
     from open3d_amd import _lib
     c = _lib.Context(0)
-    c.debug_set(use_tile_search=True, collect_tile_stats=True)
+    c.debug_set(use_tile_search=f32, collect_tile_stats=True)
+    c.tile_stats(reset=True)  # the counters are process-wide
     try:
         sc = make_scene(40000, 42000, cfg_id=17)
         s = sc["spacing"]
@@ -166,7 +169,7 @@ def test_tile_search_path_matches_oracle(oracle, est):
         got = reg.RegistrationICP(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=tgt_n), r,
                                   np.eye(4), estimation, reg.ICPConvergenceCriteria(), ctx=c)
         st = c.tile_stats()
-        assert st["tiled"] > 0, "the tile path did not run"
+        assert (st["tiled"] > 0) == f32, "wrong search kernel ran"
         ref = oracle.registration_icp(sc["source"], sc["target"], r, None, est_type, tgt_n)
         assert got.iterations_ == ref.iterations
         assert np.array_equal(got.corr_, ref.corr)
