@@ -54,8 +54,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--estimation", default="p2plane", choices=["p2plane", "p2p"])
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--search", default="f32", choices=["f32", "f64"],
                     help="f32: fp32 prefilter search + fp64 confirmation + exact fixup (default); f64: per-lane fp64 search")
