@@ -97,6 +97,37 @@ O3D_API int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64
                               double max_correspondence_distance, const double transformation_colmajor[16], int mem,
                               int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
 
+/* RegistrationICP over a batch of independent pairs (BASELINE config 5: thousands of small fragment pairs; the reference
+ * would call Registration.cpp:129-168 in a loop).  Pair p uses src_xyz[p] (n_src[p] points), tgt_xyz[p], tgt_nrm[p]
+ * (n_tgt[p] points; tgt_nrm may be NULL for point-to-point), init_colmajor + 16 p (init_colmajor NULL: identity) and
+ * writes out_transformation + 16 p, out_fitness[p], out_inlier_rmse[p], out_iterations[p], out_n_corr[p] and, when
+ * out_corr and out_corr[p] are non-NULL, n_src[p] correspondences.  The pairs are spread over `n_workers` host threads
+ * (0: default 4), each with its own context and stream on ctx's device, so that the set-up of one pair overlaps the
+ * loop of another.  out_status[p] (may be NULL) receives the pair's status; the return value is the first non-zero one. */
+O3D_API int o3d_registration_icp_batch(o3d_ctx *ctx, int64_t n_pairs, const double *const *src_xyz, const int64_t *n_src,
+                               const double *const *tgt_xyz, const double *const *tgt_nrm, const int64_t *n_tgt,
+                               double max_correspondence_distance, const double *init_colmajor, int estimation,
+                               int with_scaling, double relative_fitness, double relative_rmse, int max_iteration, int mem,
+                               int n_workers, double *out_transformation, int32_t *const *out_corr, int64_t *out_n_corr,
+                               double *out_fitness, double *out_inlier_rmse, int *out_iterations, int *out_status);
+
+/* TransformationEstimationPointToPoint / PointToPlane::ComputeTransformation, TransformationEstimation.cpp:49-60,74-98
+ * (with utility::ComputeJTJandJTr utility/Eigen.cpp:159-201 and SolveJacobianSystemAndObtainExtrinsicMatrix :116-130),
+ * over a caller-given CorrespondenceSet: corres_pairs = n_corres x int32[2] (source index, target index), the storage of
+ * std::vector<Eigen::Vector2i>.  Identity when n_corres == 0 or point-to-plane without target normals (:51-52,76-77). */
+O3D_API int o3d_compute_transformation(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz,
+                               const double *tgt_nrm, int64_t n_tgt, const int32_t *corres_pairs, int64_t n_corres,
+                               int estimation, int with_scaling, int mem, double out_transformation[16]);
+/* TransformationEstimationPointToPoint / PointToPlane::ComputeRMSE, TransformationEstimation.cpp:38-47,62-72. */
+O3D_API int o3d_compute_rmse(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                     int64_t n_tgt, const int32_t *corres_pairs, int64_t n_corres, int estimation, int mem, double *out_rmse);
+
+/* GetInformationMatrixFromPointClouds, pipelines/registration/Registration.cpp:303-355.  out_gtg: 36 doubles (6x6,
+ * symmetric, so row- and column-major agree). */
+O3D_API int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                           double max_correspondence_distance, const double transformation_colmajor[16], int mem,
+                           double out_gtg[36]);
+
 /* ---- stepwise, device-resident ICP (same loop, caller owns the per-iteration
  *      exchange; used by the sharded multi-GPU driver and by bench.py) -------- */
 
@@ -124,6 +155,13 @@ O3D_API int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks)
 /* Unsharded shortcut: o3d_icp_pass + o3d_icp_solve(local sums, 1) with the partial reduction and the estimate fused
  * into one launch. */
 O3D_API int o3d_icp_step(o3d_ctx *ctx);
+/* Estimations that stay on the host (TransformationEstimationForColoredICP, user subclasses of TransformationEstimation,
+ * TransformationEstimation.h:57-80): the caller runs o3d_icp_pass, reads the correspondences and the fitness / rmse of
+ * that pass (Registration.cpp:82-89) with o3d_icp_fetch, calls its own ComputeTransformation and hands the update back
+ * with o3d_icp_set_update, which composes it into the transformation and applies it to the source in the next pass
+ * (Registration.cpp:158-159).  The convergence test (:162-165) is the caller's. */
+O3D_API int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
+O3D_API int o3d_icp_set_update(o3d_ctx *ctx, const double update_colmajor[16]);
 /* Synchronise and report whether the loop has ended (converged or max_iteration reached). */
 O3D_API int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes);
 /* Synchronise and fetch the RegistrationResult (Registration.h:107-126).  out_corr (n_src entries, `mem` space, may be

@@ -33,6 +33,18 @@ _SIGNATURES = {
                                        C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int)]),
     "o3d_evaluate_registration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp,
                                             C.c_int, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp]),
+    "o3d_registration_icp_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
+    "o3d_compute_transformation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_int64, C.c_int, C.c_int, C.c_int, c_dp]),
+    "o3d_compute_rmse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                   C.c_int, C.c_int, c_dp]),
+    "o3d_information_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp, C.c_int,
+                                         c_dp]),
+    "o3d_icp_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp]),
+    "o3d_icp_set_update": (C.c_int, [C.c_void_p, c_dp]),
     "o3d_icp_setup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, c_dp,
                                 C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64]),
     "o3d_icp_pass": (C.c_int, [C.c_void_p]),

@@ -89,7 +89,15 @@ struct Matrix4d {  // column-major, like Eigen::Matrix4d
   const double *data() const { return m; }
   double *data() { return m; }
 };
-static_assert(sizeof(Vector3d) == 24 && sizeof(Vector2i) == 8 && sizeof(Matrix4d) == 128, "layout must match Eigen's");
+struct Matrix6d {  // column-major, like Eigen::Matrix6d (utility/Eigen.h:38)
+  double m[36];
+  double &operator()(int r, int c) { return m[c * 6 + r]; }
+  double operator()(int r, int c) const { return m[c * 6 + r]; }
+  const double *data() const { return m; }
+  double *data() { return m; }
+};
+static_assert(sizeof(Vector3d) == 24 && sizeof(Vector2i) == 8 && sizeof(Matrix4d) == 128 && sizeof(Matrix6d) == 288,
+              "layout must match Eigen's");
 
 namespace geometry {
 
@@ -140,6 +148,7 @@ using geometry::KDTreeSearchParamKNN;
 using geometry::KDTreeSearchParamRadius;
 using geometry::PointCloud;
 using Mat4 = Matrix4d;
+using Mat6 = Matrix6d;
 using Vec2i = Vector2i;
 using Vec3 = Vector3d;
 }  // namespace o3d_types
@@ -151,6 +160,7 @@ using open3d::geometry::KDTreeSearchParamKNN;
 using open3d::geometry::KDTreeSearchParamRadius;
 using open3d::geometry::PointCloud;
 using Mat4 = Eigen::Matrix4d;
+using Mat6 = Eigen::Matrix6d;
 using Vec2i = Eigen::Vector2i;
 using Vec3 = Eigen::Vector3d;
 }  // namespace o3d_types
@@ -210,23 +220,72 @@ namespace registration {
 
 #ifndef O3D_AMD_USE_OPEN3D_TYPES
 typedef std::vector<Vector2i> CorrespondenceSet;  // TransformationEstimation.h:43
+#else
+using open3d::pipelines::registration::CorrespondenceSet;
+#endif
 
+// TransformationEstimationPointToPoint / PointToPlane::ComputeTransformation and ComputeRMSE on the device
+// (TransformationEstimation.cpp:38-98).  estimation: O3D_EST_POINT_TO_POINT / O3D_EST_POINT_TO_PLANE.  Inside the reference
+// tree the four member functions become one-line calls of these two.
+inline o3d_types::Mat4 ComputeTransformationOnDevice(int estimation, bool with_scaling, const o3d_types::PointCloud &source,
+                                                     const o3d_types::PointCloud &target, const CorrespondenceSet &corres,
+                                                     Context &c = Context::Default()) {
+  o3d_types::Mat4 T;
+  Check(c.get(), o3d_compute_transformation(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                            (const double *)target.points_.data(),
+                                            target.HasNormals() ? (const double *)target.normals_.data() : nullptr,
+                                            (int64_t)target.points_.size(), (const int32_t *)corres.data(), (int64_t)corres.size(),
+                                            estimation, with_scaling ? 1 : 0, O3D_MEM_HOST, T.data()));
+  return T;
+}
+inline double ComputeRMSEOnDevice(int estimation, const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                  const CorrespondenceSet &corres, Context &c = Context::Default()) {
+  double rmse = 0.0;
+  Check(c.get(), o3d_compute_rmse(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                  (const double *)target.points_.data(),
+                                  target.HasNormals() ? (const double *)target.normals_.data() : nullptr,
+                                  (int64_t)target.points_.size(), (const int32_t *)corres.data(), (int64_t)corres.size(), estimation,
+                                  O3D_MEM_HOST, &rmse));
+  return rmse;
+}
+
+#ifndef O3D_AMD_USE_OPEN3D_TYPES
 enum class TransformationEstimationType { Unspecified = 0, PointToPoint = 1, PointToPlane = 2, ColoredICP = 3 };  // :45-50
 
 class TransformationEstimation {  // :57-80
  public:
   virtual ~TransformationEstimation() {}
   virtual TransformationEstimationType GetTransformationEstimationType() const = 0;
+  virtual double ComputeRMSE(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                             const CorrespondenceSet &corres) const = 0;
+  virtual Matrix4d ComputeTransformation(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                                         const CorrespondenceSet &corres) const = 0;
 };
 class TransformationEstimationPointToPoint : public TransformationEstimation {  // :85-107
  public:
   explicit TransformationEstimationPointToPoint(bool with_scaling = false) : with_scaling_(with_scaling) {}
   TransformationEstimationType GetTransformationEstimationType() const override { return TransformationEstimationType::PointToPoint; }
+  double ComputeRMSE(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                     const CorrespondenceSet &corres) const override {
+    return ComputeRMSEOnDevice(O3D_EST_POINT_TO_POINT, source, target, corres);
+  }
+  Matrix4d ComputeTransformation(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                                 const CorrespondenceSet &corres) const override {
+    return ComputeTransformationOnDevice(O3D_EST_POINT_TO_POINT, with_scaling_, source, target, corres);
+  }
   bool with_scaling_ = false;
 };
 class TransformationEstimationPointToPlane : public TransformationEstimation {  // :112-130
  public:
   TransformationEstimationType GetTransformationEstimationType() const override { return TransformationEstimationType::PointToPlane; }
+  double ComputeRMSE(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                     const CorrespondenceSet &corres) const override {
+    return ComputeRMSEOnDevice(O3D_EST_POINT_TO_PLANE, source, target, corres);
+  }
+  Matrix4d ComputeTransformation(const geometry::PointCloud &source, const geometry::PointCloud &target,
+                                 const CorrespondenceSet &corres) const override {
+    return ComputeTransformationOnDevice(O3D_EST_POINT_TO_PLANE, false, source, target, corres);
+  }
 };
 
 class ICPConvergenceCriteria {  // Registration.h:54-76
@@ -246,7 +305,6 @@ class RegistrationResult {  // Registration.h:107-126
   double inlier_rmse_, fitness_;
 };
 #else
-using open3d::pipelines::registration::CorrespondenceSet;
 using open3d::pipelines::registration::ICPConvergenceCriteria;
 using open3d::pipelines::registration::RegistrationResult;
 using open3d::pipelines::registration::TransformationEstimation;
@@ -261,10 +319,54 @@ inline void ExpandCorrespondences(const std::vector<int32_t> &corr, Corresponden
   for (size_t i = 0; i < corr.size(); i++)  // ascending source index: the reference's serial order (Registration.cpp:60-68)
     if (corr[i] >= 0) out.push_back(o3d_types::Vec2i((int)i, corr[i]));
 }
+
+// Column-major 4x4 helpers on raw storage (the same code serves Eigen::Matrix4d and the stand-in).
+inline void MatMul4(const double *A, const double *B, double *C) {
+  double r[16];
+  for (int c = 0; c < 4; c++)
+    for (int i = 0; i < 4; i++) {
+      double v = 0.0;
+      for (int k = 0; k < 4; k++) v += A[k * 4 + i] * B[c * 4 + k];
+      r[c * 4 + i] = v;
+    }
+  for (int i = 0; i < 16; i++) C[i] = r[i];
+}
+inline bool IsIdentity4(const double *T) {  // Eigen isIdentity(), dummy_precision 1e-12
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      const double v = T[c * 4 + r];
+      if (r == c) {
+        if (!(std::fabs(v - 1.0) <= 1e-12 * std::fmin(std::fabs(v), 1.0))) return false;
+      } else if (!(std::fabs(v) <= 1e-12)) {
+        return false;
+      }
+    }
+  return true;
+}
+// PointCloud::Transform, geometry/Geometry3D.cpp:77-89 (points: homogeneous divide; normals: rotation part only)
+inline void TransformCloud(o3d_types::PointCloud &pcd, const double *T) {
+  double *p = (double *)pcd.points_.data();
+  for (size_t i = 0; i < pcd.points_.size(); i++, p += 3) {
+    const double x = p[0], y = p[1], z = p[2];
+    const double w = T[3] * x + T[7] * y + T[11] * z + T[15];
+    p[0] = (T[0] * x + T[4] * y + T[8] * z + T[12]) / w;
+    p[1] = (T[1] * x + T[5] * y + T[9] * z + T[13]) / w;
+    p[2] = (T[2] * x + T[6] * y + T[10] * z + T[14]) / w;
+  }
+  if (pcd.HasNormals()) {
+    double *n = (double *)pcd.normals_.data();
+    for (size_t i = 0; i < pcd.normals_.size(); i++, n += 3) {
+      const double x = n[0], y = n[1], z = n[2];
+      n[0] = T[0] * x + T[4] * y + T[8] * z;
+      n[1] = T[1] * x + T[5] * y + T[9] * z;
+      n[2] = T[2] * x + T[6] * y + T[10] * z;
+    }
+  }
+}
 }  // namespace detail
 
-// True when the estimation runs on the device path (anything else -- ColoredICP, user subclasses -- must keep using the
-// reference's own RegistrationICP; INTEGRATION.md shows the dispatch).
+// True when the whole loop runs on the device.  Any other estimation (ColoredICP, user subclasses) still gets its
+// correspondence search from the device: RegistrationICP below then calls the virtual ComputeTransformation on the host.
 inline bool IsAccelerated(const TransformationEstimation &e) {
   const auto t = e.GetTransformationEstimationType();
   return t == TransformationEstimationType::PointToPoint || t == TransformationEstimationType::PointToPlane;
@@ -286,6 +388,46 @@ inline RegistrationResult EvaluateRegistration(const o3d_types::PointCloud &sour
   return result;
 }
 
+// Registration.cpp:129-168 for an estimation whose ComputeTransformation stays on the host: LOOP-A (the correspondence
+// search, :41-91) on the device through o3d_icp_pass / o3d_icp_fetch, the virtual call on `pcd` exactly as the reference
+// makes it (:157), the update handed back with o3d_icp_set_update (:158-159), convergence test (:162-165) here.
+inline RegistrationResult RegistrationICPHostEstimation(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                                        double max_correspondence_distance, const o3d_types::Mat4 &init,
+                                                        const TransformationEstimation &estimation,
+                                                        const ICPConvergenceCriteria &criteria, Context &c = Context::Default()) {
+  if (max_correspondence_distance <= 0.0) throw std::runtime_error(o3d_status_string(O3D_ERR_INVALID_DISTANCE));
+  if (estimation.GetTransformationEstimationType() == TransformationEstimationType::ColoredICP && !target.HasNormals())
+    throw std::runtime_error(o3d_status_string(O3D_ERR_NEED_NORMALS));
+  const int64_t ns = (int64_t)source.points_.size();
+  Check(c.get(), o3d_icp_setup(c.get(), (const double *)source.points_.data(), ns, (const double *)target.points_.data(), nullptr,
+                               (int64_t)target.points_.size(), max_correspondence_distance, init.data(), O3D_EST_POINT_TO_POINT, 0,
+                               0.0, 0.0, 1 << 20, O3D_MEM_HOST, ns));
+  o3d_types::PointCloud pcd = source;
+  if (!detail::IsIdentity4(init.data())) detail::TransformCloud(pcd, init.data());
+  RegistrationResult result(init);
+  std::vector<int32_t> corr((size_t)ns);
+  int64_t nc = 0;
+  auto pass = [&](RegistrationResult &r) {
+    Check(c.get(), o3d_icp_pass(c.get()));
+    Check(c.get(), o3d_icp_fetch(c.get(), O3D_MEM_HOST, corr.data(), &nc, &r.fitness_, &r.inlier_rmse_));
+    detail::ExpandCorrespondences(corr, r.correspondence_set_);
+  };
+  pass(result);
+  o3d_types::Mat4 T = init;
+  for (int i = 0; i < criteria.max_iteration_; i++) {
+    const o3d_types::Mat4 update = estimation.ComputeTransformation(pcd, target, result.correspondence_set_);
+    detail::MatMul4(update.data(), T.data(), T.data());
+    detail::TransformCloud(pcd, update.data());
+    Check(c.get(), o3d_icp_set_update(c.get(), update.data()));
+    const double pf = result.fitness_, pr = result.inlier_rmse_;
+    pass(result);
+    result.transformation_ = T;
+    if (std::fabs(pf - result.fitness_) < criteria.relative_fitness_ && std::fabs(pr - result.inlier_rmse_) < criteria.relative_rmse_)
+      break;
+  }
+  return result;
+}
+
 // RegistrationICP, Registration.cpp:129-168
 inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                           double max_correspondence_distance,
@@ -293,8 +435,7 @@ inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, c
                                           const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false),
                                           const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria(),
                                           Context &c = Context::Default()) {
-  if (!IsAccelerated(estimation))
-    throw std::runtime_error("open3d_amd: only point-to-point and point-to-plane estimation run on the device path");
+  if (!IsAccelerated(estimation)) return RegistrationICPHostEstimation(source, target, max_correspondence_distance, init, estimation, criteria, c);
   const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
   int with_scaling = 0;
   if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
@@ -313,6 +454,65 @@ inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, c
   for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
   detail::ExpandCorrespondences(corr, result.correspondence_set_);
   return result;
+}
+
+// GetInformationMatrixFromPointClouds, Registration.cpp:303-355
+inline o3d_types::Mat6 GetInformationMatrixFromPointClouds(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                                           double max_correspondence_distance,
+                                                           const o3d_types::Mat4 &transformation, Context &c = Context::Default()) {
+  o3d_types::Mat6 GTG;
+  Check(c.get(), o3d_information_matrix(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                        (const double *)target.points_.data(), (int64_t)target.points_.size(),
+                                        max_correspondence_distance, transformation.data(), O3D_MEM_HOST, GTG.data()));
+  return GTG;
+}
+
+// RegistrationICP over independent pairs (no counterpart in the reference, which would loop over Registration.cpp:129-168):
+// results[p] as the single call on (sources[p], targets[p], inits[p]) would give.  inits empty: identity for every pair.
+inline std::vector<RegistrationResult> RegistrationICPBatch(const std::vector<const o3d_types::PointCloud *> &sources,
+                                                            const std::vector<const o3d_types::PointCloud *> &targets,
+                                                            double max_correspondence_distance,
+                                                            const std::vector<o3d_types::Mat4> &inits = {},
+                                                            const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false),
+                                                            const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria(),
+                                                            int n_workers = 0, Context &c = Context::Default()) {
+  if (!IsAccelerated(estimation)) throw std::runtime_error("open3d_amd: RegistrationICPBatch needs a point-to-point or point-to-plane estimation");
+  const size_t n = sources.size();
+  if (targets.size() != n || (!inits.empty() && inits.size() != n)) throw std::runtime_error("open3d_amd: RegistrationICPBatch: size mismatch");
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  int with_scaling = 0;
+  if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
+  std::vector<const double *> src(n), tgt(n), nrm(n);
+  std::vector<int64_t> ns(n), nt(n), ncorr(n);
+  std::vector<std::vector<int32_t>> corr(n);
+  std::vector<int32_t *> corr_ptr(n);
+  std::vector<double> init_flat(inits.empty() ? 0 : 16 * n), T(16 * n), fit(n), rmse(n);
+  std::vector<int> iters(n), status(n);
+  for (size_t p = 0; p < n; p++) {
+    src[p] = (const double *)sources[p]->points_.data();
+    tgt[p] = (const double *)targets[p]->points_.data();
+    nrm[p] = targets[p]->HasNormals() ? (const double *)targets[p]->normals_.data() : nullptr;
+    ns[p] = (int64_t)sources[p]->points_.size();
+    nt[p] = (int64_t)targets[p]->points_.size();
+    corr[p].resize(sources[p]->points_.size());
+    corr_ptr[p] = corr[p].data();
+    if (!inits.empty())
+      for (int i = 0; i < 16; i++) init_flat[16 * p + i] = inits[p].data()[i];
+  }
+  Check(c.get(), o3d_registration_icp_batch(c.get(), (int64_t)n, src.data(), ns.data(), tgt.data(), nrm.data(), nt.data(),
+                                            max_correspondence_distance, inits.empty() ? nullptr : init_flat.data(),
+                                            p2l ? O3D_EST_POINT_TO_PLANE : O3D_EST_POINT_TO_POINT, with_scaling,
+                                            criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, O3D_MEM_HOST,
+                                            n_workers, T.data(), corr_ptr.data(), ncorr.data(), fit.data(), rmse.data(), iters.data(),
+                                            status.data()));
+  std::vector<RegistrationResult> out(n);
+  for (size_t p = 0; p < n; p++) {
+    for (int i = 0; i < 16; i++) out[p].transformation_.data()[i] = T[16 * p + i];
+    out[p].fitness_ = fit[p];
+    out[p].inlier_rmse_ = rmse[p];
+    detail::ExpandCorrespondences(corr[p], out[p].correspondence_set_);
+  }
+  return out;
 }
 
 }  // namespace registration

@@ -5,7 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "o3d_internal.h"
 
@@ -13,6 +16,10 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
 int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset);
+int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
+int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
+                     const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad);
+int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
                                int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
 int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
@@ -129,6 +136,7 @@ const char *o3d_last_error(const o3d_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 struct o3d_ctx_full : o3d_ctx {
   o3d_staging stage;
+  std::vector<o3d_ctx *> workers;  // contexts of the batch worker threads (created on first use, kept)
 };
 static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
 
@@ -165,6 +173,8 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
 void o3d_ctx_destroy(o3d_ctx *c) {
   if (!c) return;
   o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
+  for (o3d_ctx *w : ctx->workers) o3d_ctx_destroy(w);
+  ctx->workers.clear();
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
@@ -255,6 +265,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   hs->rel_fitness = rel_fitness;
   hs->rel_rmse = rel_rmse;
   hs->n_src_global = (double)n_src_global;
+  ctx->n_src_global = n_src_global;
   hs->max_iter = max_iter;
   hs->apply_update = apply_init;
   hs->estimation = estimation;
@@ -270,6 +281,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   ctx->setup_ms[1] = ms1;
   for (auto &e : ev) (void)hipEventDestroy(e);
   ctx->enq_passes = 0;
+  ctx->sums_valid = 0;
   ctx->icp_ready = 1;
   return O3D_OK;
 }
@@ -279,6 +291,7 @@ int o3d_icp_pass(o3d_ctx *ctx) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
+  ctx->sums_valid = 1;
   return o3d_launch_pass(ctx, ctx->sums, 0);
 }
 
@@ -295,6 +308,7 @@ int o3d_icp_step(o3d_ctx *ctx) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_step before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
+  ctx->sums_valid = 1;
   return o3d_launch_pass(ctx, ctx->sums, 1);
 }
 
@@ -451,6 +465,64 @@ int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, con
   return o3d_icp_finish(ctx, mem, out_T, out_corr, out_n_corr, out_fitness, out_rmse, out_iters);
 }
 
+int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const *src_xyz, const int64_t *n_src,
+                               const double *const *tgt_xyz, const double *const *tgt_nrm, const int64_t *n_tgt, double max_dist,
+                               const double *init, int estimation, int with_scaling, double rel_fitness, double rel_rmse,
+                               int max_iter, int mem, int n_workers, double *out_T, int32_t *const *out_corr, int64_t *out_n_corr,
+                               double *out_fitness, double *out_rmse, int *out_iters, int *out_status) {
+  if (!c) return O3D_ERR_INVALID_ARG;
+  o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
+  if (n_pairs < 0 || (n_pairs > 0 && (!src_xyz || !n_src || !tgt_xyz || !n_tgt)))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
+  if (n_pairs == 0) return O3D_OK;
+  if (n_workers <= 0) n_workers = 4;
+  if (n_workers > 16) n_workers = 16;
+  if ((int64_t)n_workers > n_pairs) n_workers = (int)n_pairs;
+  while ((int)ctx->workers.size() < n_workers) {
+    o3d_ctx *w = nullptr;
+    const int st = o3d_ctx_create(ctx->device, &w);
+    if (st != O3D_OK) return o3d_fail(ctx, st, "batch worker context: %s", o3d_last_error(nullptr));
+    ctx->workers.push_back(w);
+  }
+  static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::atomic<int64_t> next(0);
+  std::vector<int> first_status((size_t)n_workers, O3D_OK);
+  auto work = [&](int wi) {
+    o3d_ctx *w = ctx->workers[(size_t)wi];
+    w->use_tile = ctx->use_tile;
+    w->force_generic = ctx->force_generic;
+    for (;;) {
+      const int64_t p = next.fetch_add(1);
+      if (p >= n_pairs) break;
+      double T[16], fit = 0.0, rmse = 0.0;
+      int64_t nc = 0;
+      int iters = 0;
+      const int st = o3d_registration_icp(w, src_xyz[p], n_src[p], tgt_xyz[p], tgt_nrm ? tgt_nrm[p] : nullptr, n_tgt[p], max_dist,
+                                          init ? init + 16 * p : kIdentity, estimation, with_scaling, rel_fitness, rel_rmse,
+                                          max_iter, mem, T, (out_corr && out_corr[p]) ? out_corr[p] : nullptr, &nc, &fit, &rmse,
+                                          &iters);
+      if (out_status) out_status[p] = st;
+      if (st != O3D_OK) {
+        if (first_status[(size_t)wi] == O3D_OK) first_status[(size_t)wi] = st;
+        continue;  // the other pairs are independent
+      }
+      if (out_T) memcpy(out_T + 16 * p, T, sizeof T);
+      if (out_n_corr) out_n_corr[p] = nc;
+      if (out_fitness) out_fitness[p] = fit;
+      if (out_rmse) out_rmse[p] = rmse;
+      if (out_iters) out_iters[p] = iters;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int wi = 1; wi < n_workers; wi++) threads.emplace_back(work, wi);
+  work(0);
+  for (auto &t : threads) t.join();
+  for (int wi = 0; wi < n_workers; wi++)
+    if (first_status[(size_t)wi] != O3D_OK)
+      return o3d_fail(ctx, first_status[(size_t)wi], "batch: %s", o3d_last_error(ctx->workers[(size_t)wi]));
+  return O3D_OK;
+}
+
 int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
                               double max_dist, const double T[16], int mem, int32_t *out_corr, int64_t *out_n_corr,
                               double *out_fitness, double *out_rmse) {
@@ -473,6 +545,120 @@ int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem, n_src));
   O3D_TRY(o3d_icp_step(ctx));
   return o3d_icp_finish(ctx, mem, nullptr, out_corr, out_n_corr, out_fitness, out_rmse, nullptr);
+}
+
+
+// ---- estimations that stay on the host ---------------------------------------------------------------------------
+
+int o3d_icp_set_update(o3d_ctx *ctx, const double update_colmajor[16]) {
+  if (!ctx || !update_colmajor) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_set_update before o3d_icp_setup");
+  DeviceGuard guard(ctx->device);
+  return o3d_launch_set_update(ctx, update_colmajor);
+}
+
+int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_rmse) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (!ctx->icp_ready || !ctx->sums_valid)
+    return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_fetch must directly follow o3d_icp_pass (or o3d_icp_step) on this context");
+  DeviceGuard guard(ctx->device);
+  if (out_corr && ctx->n_src > 0) {
+    if (mem == O3D_MEM_DEVICE) {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, out_corr));
+    } else {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, ctx->corr_out));
+      O3D_HIP(ctx, hipMemcpyAsync(out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  double *hq = reinterpret_cast<double *>(ctx->pinned);
+  O3D_HIP(ctx, hipMemcpyAsync(hq, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double nc = hq[O3D_SUM_NC];
+  if (out_n_corr) *out_n_corr = (int64_t)nc;
+  if (out_fitness) *out_fitness = nc > 0.0 ? nc / (double)ctx->n_src_global : 0.0;  // Registration.cpp:82-89
+  if (out_rmse) *out_rmse = nc > 0.0 ? sqrt(hq[O3D_SUM_D2] / nc) : 0.0;
+  return O3D_OK;
+}
+
+// ---- TransformationEstimation members over a given CorrespondenceSet -----------------------------------------------
+
+static int pairs_common(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
+                        const int32_t *pairs, int64_t n_pairs, int estimation, int with_scaling, int mem, double host_out[19]) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path", estimation);
+  if (n_src < 0 || n_tgt < 0 || n_pairs < 0 || (n_pairs > 0 && (!pairs || !src_xyz || !tgt_xyz)))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
+  for (int i = 0; i < 19; i++) host_out[i] = 0.0;
+  host_out[0] = host_out[5] = host_out[10] = host_out[15] = 1.0;
+  if (n_pairs == 0) return O3D_OK;  // TransformationEstimation.cpp:40-41,51-52,64-65,76-77
+  DeviceGuard guard(ctx->device);
+  o3d_staging *sg = staging_of(ctx);
+  // Safe between the passes of a set-up loop on the same context (the host-estimation path calls it from the virtual
+  // ComputeTransformation): the staging buffers are free once o3d_icp_setup has returned; only ctx->sums is taken over.
+  ctx->sums_valid = 0;
+  const void *d_tgt, *d_nrm, *d_src, *d_pairs;
+  O3D_TRY(to_device(ctx, tgt_xyz, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[0], &sg->cap[0], &d_tgt));
+  O3D_TRY(to_device(ctx, tgt_nrm, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[1], &sg->cap[1], &d_nrm));
+  O3D_TRY(to_device(ctx, src_xyz, sizeof(double) * 3 * (size_t)n_src, mem, &sg->p[2], &sg->cap[2], &d_src));
+  O3D_TRY(to_device(ctx, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, mem, &sg->p[3], &sg->cap[3], &d_pairs));
+  int *d_bad = reinterpret_cast<int *>(ctx->sums + 24);
+  O3D_TRY(o3d_launch_pairs(ctx, (const double *)d_src, n_src, (const double *)d_tgt, (const double *)d_nrm, n_tgt,
+                           (const int32_t *)d_pairs, n_pairs, estimation, with_scaling, ctx->sums, d_bad));
+  double *hq = reinterpret_cast<double *>(ctx->pinned);
+  O3D_HIP(ctx, hipMemcpyAsync(hq, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int bad;
+  memcpy(&bad, hq + 24, sizeof bad);
+  if (bad) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "%d correspondence(s) index outside the clouds", bad);
+  for (int i = 0; i < 19; i++) host_out[i] = hq[i];
+  return O3D_OK;
+}
+
+int o3d_compute_transformation(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                               int64_t n_tgt, const int32_t *corres_pairs, int64_t n_corres, int estimation, int with_scaling,
+                               int mem, double out_transformation[16]) {
+  if (!out_transformation) return O3D_ERR_INVALID_ARG;
+  double r[19];
+  O3D_TRY(pairs_common(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, corres_pairs, n_corres, estimation, with_scaling, mem, r));
+  memcpy(out_transformation, r, sizeof(double) * 16);
+  return O3D_OK;
+}
+
+int o3d_compute_rmse(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
+                     const int32_t *corres_pairs, int64_t n_corres, int estimation, int mem, double *out_rmse) {
+  if (!out_rmse) return O3D_ERR_INVALID_ARG;
+  double r[19];
+  O3D_TRY(pairs_common(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, corres_pairs, n_corres, estimation, 0, mem, r));
+  *out_rmse = estimation == O3D_EST_POINT_TO_PLANE ? r[17] : r[16];
+  return O3D_OK;
+}
+
+// ---- GetInformationMatrixFromPointClouds, Registration.cpp:303-355 ---------------------------------------------------
+
+int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                           double max_dist, const double T[16], int mem, double out_gtg[36]) {
+  if (!ctx || !out_gtg) return O3D_ERR_INVALID_ARG;
+  for (int i = 0; i < 36; i++) out_gtg[i] = 0.0;
+  if (!(max_dist > 0.0)) return O3D_OK;  // Registration.cpp:45-47: no correspondences, GTG stays zero
+  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem, n_src));
+  O3D_TRY(o3d_icp_pass(ctx));
+  DeviceGuard guard(ctx->device);
+  O3D_TRY(o3d_launch_info(ctx, ctx->sums));
+  double *q = reinterpret_cast<double *>(ctx->pinned);
+  O3D_HIP(ctx, hipMemcpyAsync(q, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->sums_valid = 0;  // ctx->sums no longer holds the pass sums
+  const double sx = q[0], sy = q[1], sz = q[2], xx = q[3], yy = q[4], zz = q[5], xy = q[6], xz = q[7], yz = q[8], n = q[9];
+#define G(r, c) out_gtg[(r) * 6 + (c)]
+  G(0, 0) = zz + yy; G(0, 1) = -xy;     G(0, 2) = -xz;     G(0, 4) = -sz; G(0, 5) = sy;
+  G(1, 1) = zz + xx; G(1, 2) = -yz;     G(1, 3) = sz;      G(1, 5) = -sx;
+  G(2, 2) = yy + xx; G(2, 3) = -sy;     G(2, 4) = sx;
+  G(3, 3) = n; G(4, 4) = n; G(5, 5) = n;
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < r; c++) G(r, c) = G(c, r);
+#undef G
+  return O3D_OK;
 }
 
 int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel_size,

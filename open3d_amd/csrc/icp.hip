@@ -882,7 +882,175 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__res
     out[perm[p]] = corr_sorted[p];
 }
 
+// ------------------------------------------------------------------ companions of the loop
+
+// Same fixed-order reduction as k_icp_finalize, without the loop's done flag (used outside the ICP loop).
+__global__ __launch_bounds__(O3D_FIN_THREADS) void k_finalize_plain(const double *__restrict__ partials, int nparts,
+                                                                     double *__restrict__ sums) {
+  __shared__ double s[32][O3D_NSUMS];
+  finalize_sums(partials, nparts, s);
+  if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
+}
+
+// GetInformationMatrixFromPointClouds, Registration.cpp:326-346: the three rank-one terms per correspondence only
+// involve the matched target point, so GTG is a function of ten moments {x, y, z, xx, yy, zz, xy, xz, yz, 1}.
+__global__ __launch_bounds__(O3D_BLOCK) void k_info_accumulate(PassArgs a) {
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < a.n_src; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    if (a.corr[i] < 0) continue;
+    const double4 p = a.tgt[a.pos[i]];
+    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z;
+    acc[3] += p.x * p.x; acc[4] += p.y * p.y; acc[5] += p.z * p.z;
+    acc[6] += p.x * p.y; acc[7] += p.x * p.z; acc[8] += p.y * p.z;
+    acc[9] += 1.0;
+  }
+  block_reduce_store(acc, red, a.partials, blockIdx.x);
+}
+
+// TransformationEstimation::ComputeTransformation / ComputeRMSE over a caller-given CorrespondenceSet
+// (TransformationEstimation.cpp:38-98): pairs = int32 (source index, target index), any order, repeats allowed.
+struct PairArgs {
+  const double *src;
+  int64_t n_src;
+  const double *tgt;
+  const double *nrm;
+  int64_t n_tgt;
+  const int32_t *pairs;
+  int64_t n_pairs;
+  double *partials;
+  int *bad;  // number of pairs with an index out of range
+};
+
+// Fixed origin of the Umeyama moments: the target point of the first pair (any value is valid; it only has to be
+// the same in the accumulation and in the estimate).
+__device__ __forceinline__ void pairs_centre(const PairArgs &a, double (&c)[3]) {
+  c[0] = c[1] = c[2] = 0.0;
+  if (a.n_pairs > 0) {
+    const int32_t j = a.pairs[1];
+    if (j >= 0 && j < a.n_tgt)
+      for (int d = 0; d < 3; d++) {
+        const double v = a.tgt[3 * (size_t)j + d];
+        c[d] = (v == v && fabs(v) < 1e300) ? v : 0.0;
+      }
+  }
+}
+
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_pairs_accumulate(PairArgs a) {
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
+  double c0[3];
+  pairs_centre(a, c0);
+  double acc[30];
+#pragma unroll
+  for (int k = 0; k < 30; k++) acc[k] = 0.0;
+  int bad = 0;
+  for (int64_t k = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; k < a.n_pairs; k += (int64_t)gridDim.x * O3D_BLOCK) {
+    const int32_t i = a.pairs[2 * k], j = a.pairs[2 * k + 1];
+    if (i < 0 || i >= a.n_src || j < 0 || j >= a.n_tgt) { bad++; continue; }
+    const double x = a.src[3 * (size_t)i], y = a.src[3 * (size_t)i + 1], z = a.src[3 * (size_t)i + 2];
+    const double4 p = make_double4(a.tgt[3 * (size_t)j], a.tgt[3 * (size_t)j + 1], a.tgt[3 * (size_t)j + 2], 0.0);
+    Best b;
+    const double dx = x - p.x, dy = y - p.y, dz = z - p.z;
+    double d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    b.d2 = d2; b.idx = j; b.pos = (uint32_t)j;
+    accumulate<EST>(acc, x, y, z, b, p, a.nrm, c0[0], c0[1], c0[2]);
+  }
+  if (bad) atomicAdd(a.bad, bad);
+  block_reduce_store(acc, red, a.partials, blockIdx.x);
+}
+
+// out[0..15] = ComputeTransformation (column-major), out[16] = point-to-point RMSE, out[17] = point-to-plane RMSE,
+// out[18] = number of pairs used.
+__global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, int nparts, int estimation, int with_scaling,
+                                                                     double *__restrict__ out) {
+  __shared__ double s[32][O3D_NSUMS];
+  finalize_sums(a.partials, nparts, s);
+  if (threadIdx.x != 0) return;
+  double q[O3D_NSUMS];
+  for (int k = 0; k < O3D_NSUMS; k++) q[k] = s[0][k];
+  double c0[3];
+  pairs_centre(a, c0);
+  double T[16];
+  mat4_identity(T);
+  const double nc = q[O3D_SUM_NC];
+  if (nc > 0.0) {
+    if (estimation == O3D_EST_POINT_TO_PLANE) {
+      if (a.nrm) {
+        double A[36], b[6], x[6];
+        int k = 0;
+        for (int r = 0; r < 6; r++)
+          for (int c = r; c < 6; c++) { A[r * 6 + c] = q[k]; A[c * 6 + r] = q[k]; k++; }
+        for (int r = 0; r < 6; r++) b[r] = -q[21 + r];
+        ldlt_solve6(A, b, x);
+        vec6_to_mat4(x, T);
+      }
+    } else {
+      umeyama_from_sums(q, c0, with_scaling, T);
+    }
+  }
+  for (int i = 0; i < 16; i++) out[i] = T[i];
+  out[16] = nc > 0.0 ? sqrt(q[O3D_SUM_D2] / nc) : 0.0;
+  out[17] = (nc > 0.0 && a.nrm) ? sqrt(q[27] / nc) : 0.0;
+  out[18] = nc;
+}
+
+// Caller-computed update (estimations that stay on the host, e.g. ColoredICP or a user subclass): what
+// Registration.cpp:157-159 does with the result of the virtual ComputeTransformation.
+struct Mat16 {
+  double m[16];
+};
+__global__ void k_icp_set_update(IcpState *__restrict__ st, Mat16 u) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) st->update[i] = u.m[i];
+  mat4_mul(u.m, st->T, st->T);
+  st->apply_update = 1;
+  st->iters = st->iters + 1;
+}
+
 }  // namespace
+
+int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out) {
+  PassArgs pa{};
+  pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.corr = ctx->corr_sorted; pa.pos = ctx->pos_sorted;
+  pa.partials = ctx->partials;
+  const int g = ctx->pass_grid;
+  hipLaunchKernelGGL(k_info_accumulate, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+  hipLaunchKernelGGL(k_finalize_plain, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, g, dev_sums_out);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+// dev_out: 19 doubles (see k_pairs_estimate); dev_bad: one int, zeroed here.
+int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
+                     const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad) {
+  PairArgs a;
+  a.src = d_src; a.n_src = n_src; a.tgt = d_tgt; a.nrm = d_nrm; a.n_tgt = n_tgt; a.pairs = d_pairs; a.n_pairs = n_pairs;
+  a.partials = ctx->partials; a.bad = dev_bad;
+  int64_t g = (n_pairs + O3D_BLOCK - 1) / O3D_BLOCK;
+  if (g < 1) g = 1;
+  if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+  O3D_HIP(ctx, hipMemsetAsync(dev_bad, 0, sizeof(int), ctx->stream));
+  if (estimation == O3D_EST_POINT_TO_PLANE && d_nrm)
+    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_PLANE>, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_POINT>, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_pairs_estimate, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, a, (int)g, estimation, with_scaling, dev_out);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]) {
+  Mat16 u;
+  for (int i = 0; i < 16; i++) u.m[i] = update[i];
+  hipLaunchKernelGGL(k_icp_set_update, dim3(1), dim3(64), 0, ctx->stream, ctx->state, u);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const int g = ctx->pass_grid;

@@ -76,6 +76,7 @@ struct o3d_ctx {
 
   // source shard
   int64_t n_src = 0;
+  int64_t n_src_global = 0;        // fitness denominator (all shards)
   double *src_sorted = nullptr;    // 3 doubles per point, processing order
   uint32_t *src_perm = nullptr;    // processing position -> caller's index
   int32_t *corr_sorted = nullptr;  // per processing position
@@ -94,6 +95,7 @@ struct o3d_ctx {
   int icp_ready = 0;
   int max_iter = 0;
   int enq_passes = 0;
+  int sums_valid = 0;  // ctx->sums holds the sums of the last pass (o3d_icp_fetch)
   int estimation = 0;
   double thr = 0;  // (double)(float)(r*r)
   double setup_ms[2] = {0, 0};

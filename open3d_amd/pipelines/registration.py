@@ -31,8 +31,38 @@ class RegistrationResult:
         self.corr_ = None     # extra: dense int32[n_src] form (-1 = none)
 
 
+ESTIMATION_UNSPECIFIED, ESTIMATION_COLORED_ICP = 0, 3  # TransformationEstimation.h:45-50
+
+
+def _est_call(fn_name, est_type, with_scaling, source, target, corres, ctx):
+    ctx = ctx or _lib.default_context()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    nrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    pairs = np.ascontiguousarray(corres, dtype=np.int32).reshape(-1, 2)
+    if fn_name == "transformation":
+        T = np.zeros(16)
+        ctx.check(ctx._lib.o3d_compute_transformation(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), _lib.ptr(nrm), len(tgt),
+                                                      _lib.ptr(pairs), len(pairs), est_type, int(with_scaling), _lib.MEM_HOST,
+                                                      T.ctypes.data_as(_lib.c_dp)))
+        return _lib.from_colmajor(T)
+    r = C.c_double()
+    ctx.check(ctx._lib.o3d_compute_rmse(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), _lib.ptr(nrm), len(tgt),
+                                        _lib.ptr(pairs), len(pairs), est_type, _lib.MEM_HOST, C.byref(r)))
+    return r.value
+
+
 class TransformationEstimation:
+    """TransformationEstimation.h:57-80.  Subclasses other than the two below run through the generic path of
+    RegistrationICP: correspondences on the GPU, ComputeTransformation(source, target, corres) on the host."""
+
     def GetTransformationEstimationType(self):
+        return ESTIMATION_UNSPECIFIED
+
+    def ComputeRMSE(self, source, target, corres, ctx=None):
+        raise NotImplementedError
+
+    def ComputeTransformation(self, source, target, corres, ctx=None):
         raise NotImplementedError
 
 
@@ -45,6 +75,14 @@ class TransformationEstimationPointToPoint(TransformationEstimation):
     def GetTransformationEstimationType(self):
         return _lib.EST_POINT_TO_POINT
 
+    def ComputeRMSE(self, source, target, corres, ctx=None):
+        """TransformationEstimation.cpp:38-47."""
+        return _est_call("rmse", _lib.EST_POINT_TO_POINT, False, source, target, corres, ctx)
+
+    def ComputeTransformation(self, source, target, corres, ctx=None):
+        """TransformationEstimation.cpp:49-60."""
+        return _est_call("transformation", _lib.EST_POINT_TO_POINT, self.with_scaling_, source, target, corres, ctx)
+
 
 class TransformationEstimationPointToPlane(TransformationEstimation):
     """TransformationEstimation.h:112-130."""
@@ -52,6 +90,14 @@ class TransformationEstimationPointToPlane(TransformationEstimation):
 
     def GetTransformationEstimationType(self):
         return _lib.EST_POINT_TO_PLANE
+
+    def ComputeRMSE(self, source, target, corres, ctx=None):
+        """TransformationEstimation.cpp:62-72."""
+        return _est_call("rmse", _lib.EST_POINT_TO_PLANE, False, source, target, corres, ctx)
+
+    def ComputeTransformation(self, source, target, corres, ctx=None):
+        """TransformationEstimation.cpp:74-98."""
+        return _est_call("transformation", _lib.EST_POINT_TO_PLANE, False, source, target, corres, ctx)
 
 
 def _pairs(corr):
@@ -66,6 +112,8 @@ def RegistrationICP(source, target, max_correspondence_distance, init=None, esti
     estimation = estimation or TransformationEstimationPointToPoint(False)
     criteria = criteria or ICPConvergenceCriteria()
     est = estimation.GetTransformationEstimationType()
+    if est not in (_lib.EST_POINT_TO_POINT, _lib.EST_POINT_TO_PLANE):
+        return _registration_icp_host_estimation(source, target, max_correspondence_distance, init, estimation, criteria, ctx)
     src = np.ascontiguousarray(source.points_, dtype=np.float64)
     tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
     nrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
@@ -88,6 +136,124 @@ def RegistrationICP(source, target, max_correspondence_distance, init=None, esti
     res.inlier_rmse_ = rmse.value
     res.iterations_ = iters.value
     return res
+
+
+def _transform_points(points, T):
+    """PointCloud::Transform, Geometry3D.cpp:77-89 (points only)."""
+    h = points @ T[:3, :3].T + T[:3, 3]
+    w = points @ T[3, :3] + T[3, 3]
+    return h / w[:, None]
+
+
+def _registration_icp_host_estimation(source, target, max_correspondence_distance, init, estimation, criteria, ctx):
+    """Registration.cpp:129-168 for an estimation whose ComputeTransformation stays on the host (ColoredICP, user
+    subclasses): the correspondence search runs on the GPU (o3d_icp_pass / o3d_icp_fetch), the virtual call gets the
+    transformed source exactly as the reference passes `pcd`, and its result goes back with o3d_icp_set_update."""
+    if not (max_correspondence_distance > 0.0):
+        raise _lib.O3DError(1, "[Open3D ERROR] Invalid max_correspondence_distance.")
+    if estimation.GetTransformationEstimationType() == ESTIMATION_COLORED_ICP and not target.HasNormals():
+        raise _lib.O3DError(2, ctx._lib.o3d_status_string(2).decode())
+    sess = IcpSession(ctx)
+    big = ICPConvergenceCriteria(0.0, 0.0, 1 << 20)  # the loop bound and the convergence test are applied here
+    sess.setup(source.points_, target.points_, None, max_correspondence_distance, init, TransformationEstimationPointToPoint(),
+               big)
+    pcd = PointCloud(np.array(source.points_, dtype=np.float64))
+    for name in ("normals_", "colors_"):
+        if getattr(source, name, None) is not None and len(getattr(source, name)):
+            setattr(pcd, name, np.array(getattr(source, name), dtype=np.float64))
+    T = np.array(init, dtype=np.float64)
+    if not _is_identity(T):
+        pcd.points_ = _transform_points(pcd.points_, T)
+        if pcd.HasNormals():
+            pcd.normals_ = pcd.normals_ @ T[:3, :3].T
+    sess.enqueue_pass()
+    res = sess.fetch()
+    res.transformation_ = T.copy()
+    for i in range(criteria.max_iteration_):
+        update = np.asarray(estimation.ComputeTransformation(pcd, target, res.correspondence_set_), dtype=np.float64)
+        T = update @ T
+        pcd.points_ = _transform_points(pcd.points_, update)
+        if pcd.HasNormals():
+            pcd.normals_ = pcd.normals_ @ update[:3, :3].T
+        sess.set_update(update)
+        sess.enqueue_pass()
+        backup = res
+        res = sess.fetch()
+        res.transformation_ = T.copy()
+        res.iterations_ = i + 1
+        if (abs(backup.fitness_ - res.fitness_) < criteria.relative_fitness_
+                and abs(backup.inlier_rmse_ - res.inlier_rmse_) < criteria.relative_rmse_):
+            break
+    return res
+
+
+def _is_identity(T, prec=1e-12):
+    """Eigen::Matrix4d::isIdentity() with dummy_precision (Registration.cpp:123,150)."""
+    T = np.asarray(T, dtype=np.float64)
+    d = np.diag(T)
+    off = T - np.diag(d)
+    return bool(np.all(np.abs(d - 1.0) <= prec * np.minimum(np.abs(d), 1.0)) and np.all(np.abs(off) <= prec))
+
+
+def RegistrationICPBatch(sources, targets, max_correspondence_distance, inits=None, estimation=None, criteria=None,
+                         n_workers=0, want_corr=False, ctx=None):
+    """o3d_registration_icp_batch: RegistrationICP (Registration.cpp:129-168) over independent pairs (BASELINE config 5).
+    sources / targets: sequences of PointCloud; inits: optional sequence of 4x4.  Returns a list of RegistrationResult."""
+    ctx = ctx or _lib.default_context()
+    estimation = estimation or TransformationEstimationPointToPoint(False)
+    criteria = criteria or ICPConvergenceCriteria()
+    est = estimation.GetTransformationEstimationType()
+    n = len(sources)
+    if len(targets) != n:
+        raise ValueError("sources and targets differ in length")
+    src = [np.ascontiguousarray(s.points_, dtype=np.float64) for s in sources]
+    tgt = [np.ascontiguousarray(t.points_, dtype=np.float64) for t in targets]
+    nrm = [np.ascontiguousarray(t.normals_, dtype=np.float64) if t.HasNormals() else None for t in targets]
+    if est == _lib.EST_POINT_TO_PLANE and any(x is None for x in nrm):
+        raise _lib.O3DError(2, ctx._lib.o3d_status_string(2).decode())
+    VP = C.c_void_p * max(n, 1)
+    I64 = C.c_int64 * max(n, 1)
+    a_src = VP(*[x.ctypes.data for x in src])
+    a_tgt = VP(*[x.ctypes.data for x in tgt])
+    a_nrm = VP(*[(x.ctypes.data if x is not None else None) for x in nrm])
+    n_src = I64(*[len(x) for x in src])
+    n_tgt = I64(*[len(x) for x in tgt])
+    init_flat = None
+    if inits is not None:
+        init_flat = np.ascontiguousarray(np.stack([_lib.colmajor(T) for T in inits]))
+    corr = [np.empty(max(len(x), 1), np.int32) for x in src] if want_corr else None
+    a_corr = VP(*[c.ctypes.data for c in corr]) if want_corr else None
+    T = np.zeros((max(n, 1), 16))
+    nc = np.zeros(max(n, 1), np.int64)
+    fit, rmse = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    iters, status = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    ctx.check(ctx._lib.o3d_registration_icp_batch(
+        ctx.handle, n, a_src, n_src, a_tgt, a_nrm if est == _lib.EST_POINT_TO_PLANE else None, n_tgt,
+        float(max_correspondence_distance), _lib.ptr(init_flat), est, int(getattr(estimation, "with_scaling_", False)),
+        criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_, _lib.MEM_HOST, int(n_workers),
+        _lib.ptr(T), a_corr, _lib.ptr(nc), _lib.ptr(fit), _lib.ptr(rmse), _lib.ptr(iters), _lib.ptr(status)))
+    out = []
+    for p in range(n):
+        r = RegistrationResult(_lib.from_colmajor(T[p]))
+        r.fitness_, r.inlier_rmse_, r.iterations_, r.n_corr_ = float(fit[p]), float(rmse[p]), int(iters[p]), int(nc[p])
+        if want_corr:
+            r.corr_ = corr[p][: len(src[p])]
+            r.correspondence_set_ = _pairs(r.corr_)
+        out.append(r)
+    return out
+
+
+def GetInformationMatrixFromPointClouds(source, target, max_correspondence_distance, transformation, ctx=None):
+    """GetInformationMatrixFromPointClouds, Registration.cpp:303-355.  Returns the 6x6 GTG."""
+    ctx = ctx or _lib.default_context()
+    T = np.asarray(transformation, dtype=np.float64)
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    G = np.zeros(36)
+    ctx.check(ctx._lib.o3d_information_matrix(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), len(tgt),
+                                              float(max_correspondence_distance), _lib.colmajor(T).ctypes.data_as(_lib.c_dp),
+                                              _lib.MEM_HOST, G.ctypes.data_as(_lib.c_dp)))
+    return G.reshape(6, 6)
 
 
 def EvaluateRegistration(source, target, max_correspondence_distance, transformation=None, ctx=None):
@@ -158,6 +324,25 @@ class IcpSession:
     def enqueue_pass_to(self, dev_sums_ptr):
         c = self.ctx
         c.check(c._lib.o3d_icp_pass_to(c.handle, C.c_void_p(dev_sums_ptr)))
+
+    def set_update(self, update):
+        """Hand a host-computed update back to the loop (o3d_icp_set_update, Registration.cpp:158-159)."""
+        c = self.ctx
+        c.check(c._lib.o3d_icp_set_update(c.handle, _lib.colmajor(update).ctypes.data_as(_lib.c_dp)))
+
+    def fetch(self, want_corr=True):
+        """Correspondences, fitness and rmse of the last o3d_icp_pass (Registration.cpp:82-89)."""
+        c = self.ctx
+        corr = np.empty(max(self.n_src, 1), np.int32) if want_corr else None
+        nc = C.c_int64()
+        fit, rmse = C.c_double(), C.c_double()
+        c.check(c._lib.o3d_icp_fetch(c.handle, _lib.MEM_HOST, _lib.ptr(corr), C.byref(nc), C.byref(fit), C.byref(rmse)))
+        res = RegistrationResult()
+        if want_corr:
+            res.corr_ = corr[: self.n_src].copy()
+            res.correspondence_set_ = _pairs(res.corr_)
+        res.fitness_, res.inlier_rmse_, res.n_corr_ = fit.value, rmse.value, nc.value
+        return res
 
     def profile(self, enable=True):
         c = self.ctx

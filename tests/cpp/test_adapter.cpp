@@ -3,7 +3,9 @@
 // usage: test_adapter <in.bin> <out.bin>
 //   in : int64 n_src, int64 n_tgt, double radius, double voxel, src[3n], tgt[3m], tgt_normals[3m]
 //   out: p2plane {T[16], fitness, rmse, n_pairs, pairs[2*n_pairs] as double}, evaluate {fitness, rmse, n_pairs},
-//        voxel {m, pts[3m]}, normals(knn 30) {n, nrm[3n]}, error flags {3 doubles}
+//        voxel {m, pts[3m]}, normals(knn 30) {n, nrm[3n]}, error flags {3 doubles}, information matrix {36},
+//        host-estimation ICP (user subclass) {T[16], fitness, rmse, n_pairs, virtual calls}, ComputeRMSE {p2p, p2plane},
+//        batch of two pairs {T[16], fitness, rmse} x 2
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -15,6 +17,24 @@ using namespace open3d_amd;
 namespace reg = open3d_amd::pipelines::registration;
 
 static void put(std::vector<double> &o, double v) { o.push_back(v); }
+
+// A user-defined estimation (type Unspecified), as a caller of the reference may write one: the loop must call it through
+// the virtual interface with the transformed source.
+class MyEstimation : public reg::TransformationEstimation {
+ public:
+  mutable int calls = 0;
+  reg::TransformationEstimationType GetTransformationEstimationType() const override {
+    return reg::TransformationEstimationType::Unspecified;
+  }
+  double ComputeRMSE(const geometry::PointCloud &s, const geometry::PointCloud &t, const reg::CorrespondenceSet &c) const override {
+    return reg::ComputeRMSEOnDevice(O3D_EST_POINT_TO_PLANE, s, t, c);
+  }
+  Matrix4d ComputeTransformation(const geometry::PointCloud &s, const geometry::PointCloud &t,
+                                 const reg::CorrespondenceSet &c) const override {
+    calls++;
+    return reg::ComputeTransformationOnDevice(O3D_EST_POINT_TO_PLANE, false, s, t, c);
+  }
+};
 
 int main(int argc, char **argv) {
   if (argc != 3) return 2;
@@ -69,6 +89,28 @@ int main(int argc, char **argv) {
     flags[2] = std::string(x.what()).find("voxel_size <= 0") != std::string::npos;
   }
   for (double v : flags) put(out, v);
+
+  Matrix6d G = reg::GetInformationMatrixFromPointClouds(source, target, radius, r.transformation_);
+  for (int i = 0; i < 36; i++) put(out, G.m[i]);
+
+  MyEstimation mine;
+  reg::RegistrationResult h = reg::RegistrationICP(source, target, radius, Matrix4d::Identity(), mine, reg::ICPConvergenceCriteria());
+  for (int i = 0; i < 16; i++) put(out, h.transformation_.m[i]);
+  put(out, h.fitness_); put(out, h.inlier_rmse_); put(out, (double)h.correspondence_set_.size()); put(out, (double)mine.calls);
+
+  put(out, reg::TransformationEstimationPointToPoint().ComputeRMSE(source, target, r.correspondence_set_));
+  put(out, reg::TransformationEstimationPointToPlane().ComputeRMSE(source, target, r.correspondence_set_));
+
+  Matrix4d shifted = Matrix4d::Identity();
+  shifted(0, 3) = 0.25 * radius;
+  std::vector<reg::RegistrationResult> b = reg::RegistrationICPBatch({&source, &source}, {&target, &target}, radius,
+                                                                      {Matrix4d::Identity(), shifted},
+                                                                      reg::TransformationEstimationPointToPlane());
+  if (b.size() != 2) return 8;
+  for (const auto &x : b) {
+    for (int i = 0; i < 16; i++) put(out, x.transformation_.m[i]);
+    put(out, x.fitness_); put(out, x.inlier_rmse_);
+  }
 
   f = fopen(argv[2], "wb");
   if (!f) return 7;

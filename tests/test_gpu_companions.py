@@ -1,0 +1,163 @@
+"""GPU parity tests of the loop's companions: information matrix (Registration.cpp:303-355), the
+TransformationEstimation members over a given CorrespondenceSet (TransformationEstimation.cpp:38-98), the
+host-estimation path (virtual ComputeTransformation) and the batch entry point -- all through the C ABI, checked
+against the CPU oracle.  Bars as in test_gpu_icp.py: indices bit-exact, fp64 results within 1e-6 relative."""
+import numpy as np
+import pytest
+
+from conftest import make_scene, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _reg():
+    from open3d_amd import geometry, pipelines
+    return geometry, pipelines.registration
+
+
+def _pairs(corr):
+    idx = np.nonzero(corr >= 0)[0].astype(np.int32)
+    return np.stack([idx, corr[idx]], axis=1)
+
+
+@pytest.mark.parametrize("n_src,n_tgt,rs,use_T", [(5000, 6000, 3.0, True), (20000, 15000, 1.5, True), (4000, 4000, 2.0, False)])
+def test_information_matrix_matches_oracle(ctx, oracle, n_src, n_tgt, rs, use_T):
+    geometry, reg = _reg()
+    sc = make_scene(n_src, n_tgt, cfg_id=31 + n_src)
+    r = rs * sc["spacing"]
+    T = sc["T_true"] if use_T else np.eye(4)
+    got = reg.GetInformationMatrixFromPointClouds(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"]), r, T,
+                                                  ctx=ctx)
+    ref = oracle.information_matrix(sc["source"], sc["target"], r, T)
+    assert ref[3, 3] > 0
+    assert got[3, 3] == ref[3, 3] and got[4, 4] == ref[3, 3] and got[5, 5] == ref[3, 3]  # number of correspondences
+    assert rel_err(got, ref) < 1e-9
+    assert np.array_equal(got, got.T)
+
+
+def test_information_matrix_empty_cases(ctx):
+    geometry, reg = _reg()
+    sc = make_scene(1000, 1000, cfg_id=3)
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    assert not reg.GetInformationMatrixFromPointClouds(src, tgt, 0.0, np.eye(4), ctx=ctx).any()   # Registration.cpp:45-47
+    far = np.eye(4)
+    far[:3, 3] = 1e3
+    assert not reg.GetInformationMatrixFromPointClouds(src, tgt, sc["spacing"], far, ctx=ctx).any()  # no correspondences
+
+
+@pytest.mark.parametrize("n", [2000, 40000])
+def test_compute_transformation_and_rmse_match_oracle(ctx, oracle, n):
+    geometry, reg = _reg()
+    sc = make_scene(n, n + 300, cfg_id=41 + n)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    corr = oracle.correspondences(sc["source"], sc["target"], 3 * s)[0]
+    pairs = _pairs(corr)
+    source, target = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm)
+
+    p2l = reg.TransformationEstimationPointToPlane()
+    T_ref = oracle.p2plane_compute(sc["source"], sc["target"], nrm, corr)[0]
+    assert rel_err(p2l.ComputeTransformation(source, target, pairs, ctx=ctx), T_ref) < TOL
+    assert rel_err(p2l.ComputeRMSE(source, target, pairs, ctx=ctx), oracle.compute_rmse(sc["source"], sc["target"], nrm, corr, 2)) < 1e-12
+
+    for scaling in (False, True):
+        p2p = reg.TransformationEstimationPointToPoint(scaling)
+        T_ref = oracle.p2p_compute(sc["source"], sc["target"], corr, scaling)
+        assert rel_err(p2p.ComputeTransformation(source, target, pairs, ctx=ctx), T_ref) < TOL
+    assert rel_err(reg.TransformationEstimationPointToPoint().ComputeRMSE(source, target, pairs, ctx=ctx),
+                   oracle.compute_rmse(sc["source"], sc["target"], None, corr, 1)) < 1e-12
+
+    # order of the set does not matter beyond rounding; repeats are allowed (the reference sums over the set as given)
+    perm = np.random.default_rng(1).permutation(len(pairs))
+    T_ref = oracle.p2plane_compute(sc["source"], sc["target"], nrm, corr)[0]
+    assert rel_err(p2l.ComputeTransformation(source, target, pairs[perm], ctx=ctx), T_ref) < TOL
+
+
+def test_compute_transformation_edge_cases(ctx):
+    geometry, reg = _reg()
+    from open3d_amd import _lib
+    sc = make_scene(500, 500, cfg_id=2)
+    source, target = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    empty = np.zeros((0, 2), np.int32)
+    for est in (reg.TransformationEstimationPointToPoint(), reg.TransformationEstimationPointToPlane()):
+        assert np.array_equal(est.ComputeTransformation(source, target, empty, ctx=ctx), np.eye(4))   # :51-52, :76-77
+        assert est.ComputeRMSE(source, target, empty, ctx=ctx) == 0.0                                  # :40-41, :64-65
+    # point-to-plane without target normals: identity / 0 (:64-65, :76-77)
+    some = np.array([[0, 1], [2, 3], [4, 4]], np.int32)
+    p2l = reg.TransformationEstimationPointToPlane()
+    assert np.array_equal(p2l.ComputeTransformation(source, target, some, ctx=ctx), np.eye(4))
+    assert p2l.ComputeRMSE(source, target, some, ctx=ctx) == 0.0
+    with pytest.raises(_lib.O3DError):
+        reg.TransformationEstimationPointToPoint().ComputeTransformation(source, target, np.array([[0, 500]], np.int32), ctx=ctx)
+
+
+@pytest.mark.parametrize("inner", ["oracle", "device"])
+def test_host_estimation_path_matches_device_loop(ctx, oracle, inner):
+    """A user subclass of TransformationEstimation (type Unspecified) goes through o3d_icp_pass / fetch / set_update with the
+    virtual ComputeTransformation on the host; with the point-to-plane formula inside, it must reproduce the oracle's
+    RegistrationICP (same correspondences, same iteration count)."""
+    geometry, reg = _reg()
+    sc = make_scene(6000, 6500, cfg_id=77)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    calls = []
+
+    class HostPointToPlane(reg.TransformationEstimation):
+        def ComputeTransformation(self, source, target, corres, ctx_=None):
+            corr = np.full(len(source.points_), -1, np.int32)
+            corr[corres[:, 0]] = corres[:, 1]
+            calls.append(len(corres))
+            if inner == "device":  # o3d_compute_transformation on the same context, between two passes of the loop
+                return reg.TransformationEstimationPointToPlane().ComputeTransformation(source, target, corres, ctx=ctx)
+            return oracle.p2plane_compute(source.points_, target.points_, target.normals_, corr)[0]
+
+    source, target = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm)
+    init = np.eye(4)
+    init[:3, 3] = 0.3 * s
+    got = reg.RegistrationICP(source, target, 2 * s, init, HostPointToPlane(), reg.ICPConvergenceCriteria(1e-6, 1e-6, 12), ctx=ctx)
+    ref = oracle.registration_icp(sc["source"], sc["target"], 2 * s, init, 2, nrm, max_iter=12)
+    assert got.iterations_ == ref.iterations == len(calls)
+    assert np.array_equal(got.corr_, ref.corr)
+    assert rel_err(got.transformation_, ref.transformation) < TOL
+    assert rel_err(got.fitness_, ref.fitness) < TOL and rel_err(got.inlier_rmse_, ref.inlier_rmse) < TOL
+
+
+@pytest.mark.parametrize("workers", [1, 4])
+def test_batch_matches_single_calls(ctx, oracle, workers):
+    """BASELINE config 5 in miniature: independent pairs of different sizes; every pair must equal its own single call."""
+    geometry, reg = _reg()
+    sources, targets, inits, refs = [], [], [], []
+    sizes = [(3000, 3200), (500, 1500), (8000, 6000), (1200, 1200), (200, 1500), (5000, 5000), (2500, 2400)]
+    for k, (ns, nt) in enumerate(sizes):
+        sc = make_scene(ns, nt, cfg_id=100 + k, L=3.0)
+        s = sc["spacing"]
+        nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+        sources.append(geometry.PointCloud(sc["source"]))
+        targets.append(geometry.PointCloud(sc["target"], normals=nrm))
+        T0 = np.eye(4)
+        T0[:3, 3] = 0.1 * k * s
+        inits.append(T0)
+    # one radius for the whole batch, as in config 5 (pairs there share N and L)
+    r = 0.12
+    est, crit = reg.TransformationEstimationPointToPlane(), reg.ICPConvergenceCriteria(1e-6, 1e-6, 15)
+    got = reg.RegistrationICPBatch(sources, targets, r, inits, est, crit, n_workers=workers, want_corr=True, ctx=ctx)
+    assert len(got) == len(sizes)
+    for k in range(len(sizes)):
+        ref = oracle.registration_icp(sources[k].points_, targets[k].points_, r, inits[k], 2, targets[k].normals_, max_iter=15)
+        assert got[k].iterations_ == ref.iterations
+        assert np.array_equal(got[k].corr_, ref.corr)
+        assert rel_err(got[k].transformation_, ref.transformation) < TOL
+        assert rel_err(got[k].fitness_, ref.fitness) < TOL and rel_err(got[k].inlier_rmse_, ref.inlier_rmse) < TOL
+
+
+def test_batch_reports_per_pair_errors(ctx):
+    geometry, reg = _reg()
+    from open3d_amd import _lib
+    sc = make_scene(300, 300, cfg_id=9)
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    with pytest.raises(_lib.O3DError) as ei:
+        reg.RegistrationICPBatch([src, src], [tgt, tgt], -1.0, ctx=ctx)
+    assert ei.value.status == 1  # Registration.cpp:134-136
+    assert reg.RegistrationICPBatch([], [], 1.0, ctx=ctx) == []

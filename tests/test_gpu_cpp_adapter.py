@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import make_scene
+from conftest import make_scene, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,3 +51,25 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
     assert n == len(pc.points_) and np.array_equal(out[o:o + 3 * n].reshape(-1, 3), pc.normals_)
     o += 3 * n
     assert list(out[o:o + 3]) == [1.0, 1.0, 1.0], "reference error messages not surfaced as std::runtime_error"
+    o += 3
+    src_pc, tgt_pc = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm)
+    G = reg.GetInformationMatrixFromPointClouds(src_pc, tgt_pc, radius, want.transformation_, ctx=ctx)
+    assert np.array_equal(out[o:o + 36].reshape(6, 6), G)
+    o += 36
+    # user subclass through the virtual interface: same correspondences as the device loop, T within the parity bar
+    Th = out[o:o + 16].reshape(4, 4).T
+    assert rel_err(Th, want.transformation_) < 1e-6 and rel_err(out[o + 16], want.fitness_) < 1e-6
+    assert rel_err(out[o + 17], want.inlier_rmse_) < 1e-6 and int(out[o + 18]) == len(want.correspondence_set_)
+    assert int(out[o + 19]) == want.iterations_
+    o += 20
+    assert out[o] == reg.TransformationEstimationPointToPoint().ComputeRMSE(src_pc, tgt_pc, want.correspondence_set_, ctx=ctx)
+    assert out[o + 1] == reg.TransformationEstimationPointToPlane().ComputeRMSE(src_pc, tgt_pc, want.correspondence_set_, ctx=ctx)
+    o += 2
+    shifted = np.eye(4)
+    shifted[0, 3] = 0.25 * radius
+    for init in (np.eye(4), shifted):
+        w = reg.RegistrationICP(src_pc, tgt_pc, radius, init, reg.TransformationEstimationPointToPlane(), ctx=ctx)
+        assert np.array_equal(out[o:o + 16].reshape(4, 4).T, w.transformation_)
+        assert out[o + 16] == w.fitness_ and out[o + 17] == w.inlier_rmse_
+        o += 18
+    assert o == len(out)
