@@ -167,7 +167,8 @@ class Context:
     def tile_stats(self, reset=True):
         out = (C.c_uint64 * 8)()
         self.check(self._lib.o3d_debug_tile_stats(self._h, out, int(reset)))
-        keys = ["wave_iters", "tiled", "candidates", "exact_lanes", "rows", "valid_lanes", "_6", "_7"]
+        keys = ["wave_iters", "walk_trips_wave", "candidates", "exact_lanes", "walk_trips_lane", "valid_lanes",
+                "centre_trips_wave", "centre_trips_lane"]
         return dict(zip(keys, [int(v) for v in out]))
 
     @property

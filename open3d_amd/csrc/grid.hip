@@ -308,7 +308,9 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   if (n <= 0) return O3D_OK;
 
   O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
-  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * (size_t)n));
+  // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
+  O3D_HIP(ctx, hipMemsetAsync(ctx->tgt_local + n, 0, sizeof(float4) * 4, ctx->stream));
   if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
 
   const size_t ntiles = o3d_sort_num_tiles(n);

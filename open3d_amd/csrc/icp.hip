@@ -146,10 +146,9 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
 // Per-lane running sums of the next estimate for one accepted correspondence.
 template <int EST>
 __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y, double z, const Best &b,
-                                           const double4 &p, const double *__restrict__ nrm, double cx0, double cy0,
+                                           const double4 &p, double n0, double n1, double n2, double cx0, double cy0,
                                            double cz0) {
   if (EST == O3D_EST_POINT_TO_PLANE) {
-    const double n0 = nrm[3 * (size_t)b.pos], n1 = nrm[3 * (size_t)b.pos + 1], n2 = nrm[3 * (size_t)b.pos + 2];
     double r = (x - p.x) * n0;
     r = r + (y - p.y) * n1;
     r = r + (z - p.z) * n2;
@@ -197,8 +196,9 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
   }
 }
 
-// Optional counters of the wave-tile pass (tests and tuning): [0] wave-iterations, [1] tiled wave-iterations,
-// [2] staged candidates, [3] lanes that ran the exact per-lane search, [4] rows visited, [5] valid lanes.
+// Optional counters of the fp32 search (tests and tuning): [0] wave-iterations, [1] walk trips (wave level), [2] runs
+// listed, [3] lanes left to the exact fixup, [4] walk trips (lane level), [5] valid lanes, [6] centre-cell trips (wave
+// level: the maximum over lanes), [7] centre-cell trips (lane level).
 __device__ unsigned long long g_tile_stats[8];
 
 struct PassArgs {
@@ -234,6 +234,14 @@ __device__ __forceinline__ void apply_update(const double (&T)[12], const double
   const double nx_ = ((T[0] * x + T[3] * y) + T[6] * z) + T[9];
   const double ny_ = ((T[1] * x + T[4] * y) + T[7] * z) + T[10];
   const double nz_ = ((T[2] * x + T[5] * y) + T[8] * z) + T[11];
+  // Last row (0, 0, 0, 1) -- every rigid or similarity update: w is exactly 1 for finite input and the division is the
+  // identity, so it is skipped (wave-uniform branch).  For a non-finite coordinate the reference's 0 * x term makes w,
+  // and with it all three results, NaN; here the affected components alone turn non-finite: either way the point
+  // falls outside the grid and gets no correspondence.
+  if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 1.0) {
+    x = nx_; y = ny_; z = nz_;
+    return;
+  }
   const double nw_ = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
   x = nx_ / nw_; y = ny_ / nw_; z = nz_ / nw_;
 }
@@ -282,29 +290,55 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
   const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t beg = (int64_t)chunk * per;
   const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-  for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
-    const int32_t c = a.corr[i];
-    if (c >= 0 || c == O3D_CORR_CANDIDATE) {
-      const uint32_t pos = a.pos[i];
-      const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
-      const double4 p = a.tgt[pos];
+  // Software pipeline: the streamed reads of the next point (corr, pos, xyz: independent of everything) are issued
+  // together with the dependent gathers of the current one (target point and normal at pos), so that one memory
+  // latency per point is exposed instead of two.
+  int64_t i = beg + threadIdx.x;
+  int32_t c = O3D_CORR_NONE;
+  uint32_t pos = 0;
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (i < end) {
+    c = a.corr[i]; pos = a.pos[i];
+    x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
+  }
+  for (; i < end; i += O3D_BLOCK) {
+    const bool use = c >= 0 || c == O3D_CORR_CANDIDATE;
+    double4 p = make_double4(0.0, 0.0, 0.0, 0.0);
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (use) {
+      p = a.tgt[pos];
+      if (EST == O3D_EST_POINT_TO_PLANE) {
+        n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
+      }
+    }
+    const int64_t in = i + O3D_BLOCK;
+    int32_t c_next = O3D_CORR_NONE;
+    uint32_t pos_next = 0;
+    double xn = 0.0, yn = 0.0, zn = 0.0;
+    if (in < end) {
+      c_next = a.corr[in]; pos_next = a.pos[in];
+      xn = a.src[3 * in]; yn = a.src[3 * in + 1]; zn = a.src[3 * in + 2];
+    }
+    if (use) {
       Best b;
       const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
       double d2 = ddx * ddx;
       d2 = d2 + ddy * ddy;
       d2 = d2 + ddz * ddz;
       b.d2 = d2; b.idx = __double_as_longlong(p.w); b.pos = pos;
+      bool ok = true;
       if (c == O3D_CORR_CANDIDATE) {
         if (d2 < a.thr) {
           a.corr[i] = (int32_t)b.idx;
         } else {
           a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the fp32 error bound; stay exact regardless
           atomicOr(&a.pend[i >> 6], 1ull << (i & 63));
-          continue;
+          ok = false;
         }
       }
-      accumulate<EST>(acc, x, y, z, b, p, a.nrm, cx0, cy0, cz0);
+      if (ok) accumulate<EST>(acc, x, y, z, b, p, n0, n1, n2, cx0, cy0, cz0);
     }
+    c = c_next; pos = pos_next; x = xn; y = yn; z = zn;
   }
   block_reduce_store(acc, red, a.partials, chunk);
 }
@@ -340,33 +374,40 @@ struct F32State {
   uint32_t bpos;
 };
 
-// Up to four candidates of tgt_local[j, e): slots past the end are neutralised (d2 = +inf), so that `second` never
-// sees a duplicate of the winner.
+// Up to four candidates of tgt_local[j, e): one address, four 16-byte loads at immediate offsets.  Slots past the end
+// read the next cell's points (the array carries four entries of padding) and are neutralised (d2 = +inf), so that
+// `second` never sees them.  qy / qz are relative to the origin of the run's row (the caller shifts them per run).
+template <int V>
 __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_t j, uint32_t e, float qx, float qy, float qz,
-                                          int cxp, float oy, float oz, float hf, F32State &st) {
-  const uint32_t last = e - 1;
-  const uint32_t j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-  const float4 c0 = tl[j], c1 = tl[j1], c2 = tl[j2], c3 = tl[j3];
-  const float4 c[4] = {c0, c1, c2, c3};
-  const uint32_t jj[4] = {j, j1, j2, j3};
+                                          int cxp, float hf, F32State &st) {
+  const float4 *__restrict__ p = tl + j;
+  float4 c[4];
+  if (V & 1) {
+    const uint32_t last = e - 1;
+    c[0] = tl[j]; c[1] = tl[min(j + 1, last)]; c[2] = tl[min(j + 2, last)]; c[3] = tl[min(j + 3, last)];
+  } else {
+    c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+  }
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const float dx = qx - (c[u].x + (float)(__float_as_int(c[u].w) - cxp) * hf);
-    const float dy = qy - (c[u].y + oy);
-    const float dz = qz - (c[u].z + oz);
+    const float dy = qy - c[u].y;
+    const float dz = qz - c[u].z;
     float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    if (u > 0 && j + u > last) d2 = INFINITY;
+    if (u > 0 && j + u >= e) d2 = INFINITY;
     st.second = fminf(st.second, fmaxf(d2, st.best));
-    st.bpos = d2 < st.best ? jj[u] : st.bpos;
+    st.bpos = d2 < st.best ? j + u : st.bpos;
     st.best = fminf(st.best, d2);
   }
 }
 
+template <int V>
 __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridParams gp) {
   if (a.st->done) return;
   __shared__ uint32_t run_s[kMaxRuns][O3D_BLOCK];
   __shared__ uint32_t run_e[kMaxRuns][O3D_BLOCK];
   __shared__ unsigned char run_code[kMaxRuns][O3D_BLOCK];  // (dy + 1) + 3 * (dz + 1)
+  __shared__ float run_b[kMaxRuns][O3D_BLOCK];             // squared face distance of the run: re-checked when it is reached
   const int tid = threadIdx.x;
   const int apply = a.st->apply_update;
   double T[12], w[4];
@@ -401,6 +442,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
     F32State st;
     st.best = INFINITY; st.second = INFINITY; st.bpos = 0;
     int nruns = 0;
+    unsigned wtrips = 0, ltrips = 0, ctrips = 0;  // statistics only
     float qx = 0, qy = 0, qz = 0;
     const int cxp = cx + 1;  // padded x index of the query's cell
     if (inside) {
@@ -424,7 +466,8 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
         q0[r] = t4.v[0]; q1[r] = t4.v[1]; q2[r] = t4.v[2]; q3[r] = t4.v[3];
       }
       // centre cell first
-      for (uint32_t j = s1; j < s2; j += 4) scan4_f32(tl, j, s2, qx, qy, qz, cxp, 0.f, 0.f, hf, st);
+      for (uint32_t j = s1; j < s2; j += 4) scan4_f32<V>(tl, j, s2, qx, qy, qz, cxp, hf, st);
+      ctrips = (s2 - s1 + 3) >> 2;
       // conservative squared face distances (fp32, shrunk by a margin that dominates the rounding)
       float t;
       t = fmaxf(qx - margin, 0.f); const float axm = t * t;
@@ -434,11 +477,14 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
       t = fmaxf(qz - margin, 0.f); const float azm = t * t;
       t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
       const float reach = fminf(st.best, thrf + err) + 4.0f * err;
-      if (axm <= reach && s0 < s1) { run_s[nruns][tid] = s0; run_e[nruns][tid] = s1; run_code[nruns][tid] = 4; nruns++; }
-      if (axp <= reach && s2 < s3) { run_s[nruns][tid] = s2; run_e[nruns][tid] = s3; run_code[nruns][tid] = 4; nruns++; }
+      if (axm <= reach && s0 < s1) { run_s[nruns][tid] = s0; run_e[nruns][tid] = s1; run_code[nruns][tid] = 4; run_b[nruns][tid] = axm; nruns++; }
+      if (axp <= reach && s2 < s3) { run_s[nruns][tid] = s2; run_e[nruns][tid] = s3; run_code[nruns][tid] = 4; run_b[nruns][tid] = axp; nruns++; }
+      // face neighbours before edge neighbours: a lane that starts with a poor bound (empty centre cell) tightens it on
+      // the nearest rows and skips the others when it reaches them
+      constexpr int kRowOrder[8] = {3, 5, 1, 7, 0, 2, 6, 8};
 #pragma unroll
-      for (int r = 0; r < 9; r++) {
-        if (r == 4) continue;
+      for (int ro = 0; ro < 8; ro++) {
+        const int r = kRowOrder[ro];
         const int dy = r % 3 - 1, dz = r / 3 - 1;
         const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
         const int zz = cz + dz, yy = cy + dy;
@@ -448,35 +494,39 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
           if (s < e) {
             run_s[nruns][tid] = s; run_e[nruns][tid] = e;
             run_code[nruns][tid] = (unsigned char)r;
+            run_b[nruns][tid] = byz;
             nruns++;
           }
         }
       }
     }
-    // flattened walk over the lane's surviving runs (LDS columns are lane-private: no barrier needed)
+    // flattened walk over the lane's surviving runs (LDS columns are lane-private: no barrier needed).  A run is
+    // re-checked against the bound the lane has reached by then and dropped if it can no longer matter.
     {
       int li = 0;
       uint32_t j = 0, e = 0;
-      float oy = 0.f, oz = 0.f;
-      bool active = li < nruns;
-      if (active) {
-        j = run_s[0][tid]; e = run_e[0][tid];
-        const int code = run_code[0][tid];
-        oy = (float)(code % 3 - 1) * hf; oz = (float)(code / 3 - 1) * hf;
-      }
-      while (__any(active)) {
-        if (active) {
-          scan4_f32(tl, j, e, qx, qy, qz, cxp, oy, oz, hf, st);
-          j += 4;
-          if (j >= e) {
-            li++;
-            active = li < nruns;
-            if (active) {
+      float qyr = 0.f, qzr = 0.f;
+      bool more = nruns > 0;
+      while (__any(more)) {
+        wtrips++;
+        if (more) {
+#pragma unroll
+          for (int attempt = 0; attempt < 2; attempt++) {
+            if (j >= e && li < nruns) {
+              const float b = run_b[li][tid];
               j = run_s[li][tid]; e = run_e[li][tid];
               const int code = run_code[li][tid];
-              oy = (float)(code % 3 - 1) * hf; oz = (float)(code / 3 - 1) * hf;
+              li++;
+              if ((V & 2) && b > fminf(st.best, thrf + err) + 4.0f * err) e = j;  // cannot matter any more
+              qyr = qy - (float)(code % 3 - 1) * hf; qzr = qz - (float)(code / 3 - 1) * hf;
             }
           }
+          if (j < e) {
+            ltrips++;
+            scan4_f32<V>(tl, j, e, qx, qyr, qzr, cxp, hf, st);
+            j += 4;
+          }
+          more = (j < e) || (li < nruns);
         }
       }
     }
@@ -486,17 +536,33 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
       if (st.best <= thrf + err && (near_tie || near_thr)) verdict = O3D_CORR_PENDING;
       else if (st.best < thrf) verdict = O3D_CORR_CANDIDATE;
     }
-    if (a.stats) {
+    if (a.stats & 8) {  // histogram of per-lane trips (centre + walk): bins <=2, 3-4, 5-6, 7-8, 9-12, >12; [6] = waves, [7] = sum of wave max
+      const unsigned t = ltrips + ctrips;
+      const int bin = t <= 2 ? 0 : (t <= 4 ? 1 : (t <= 6 ? 2 : (t <= 8 ? 3 : (t <= 12 ? 4 : 5))));
+      if (valid) atomicAdd(&g_tile_stats[bin], 1ull);
+      unsigned m = t;
+      for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, O3D_WAVE));
+      if ((tid & 63) == 0) { atomicAdd(&g_tile_stats[6], 1ull); atomicAdd(&g_tile_stats[7], (unsigned long long)m); }
+    } else if (a.stats) {
       const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
-      unsigned long long rsum = (unsigned long long)nruns;
+      unsigned long long rsum = (unsigned long long)nruns, lsum = ltrips, csum = ctrips;
+      unsigned cmax = ctrips;
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) rsum += __shfl_xor(rsum, d, O3D_WAVE);
+      for (int d = 32; d >= 1; d >>= 1) {
+        rsum += __shfl_xor(rsum, d, O3D_WAVE);
+        lsum += __shfl_xor(lsum, d, O3D_WAVE);
+        csum += __shfl_xor(csum, d, O3D_WAVE);
+        cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, d, O3D_WAVE));
+      }
       if ((tid & 63) == 0) {
         atomicAdd(&g_tile_stats[0], 1ull);
-        atomicAdd(&g_tile_stats[1], 1ull);
+        atomicAdd(&g_tile_stats[1], (unsigned long long)wtrips);
         atomicAdd(&g_tile_stats[2], rsum);
         atomicAdd(&g_tile_stats[3], np);
+        atomicAdd(&g_tile_stats[4], lsum);
         atomicAdd(&g_tile_stats[5], nv);
+        atomicAdd(&g_tile_stats[6], (unsigned long long)cmax);
+        atomicAdd(&g_tile_stats[7], csum);
       }
     }
     if (valid) {
@@ -562,7 +628,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams 
         nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
         a.corr[i] = (int32_t)b.idx;
         a.pos[i] = b.pos;
-        if (b.idx >= 0) accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], a.nrm, cx0, cy0, cz0);
+        if (b.idx >= 0) {
+          double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+          if (EST == O3D_EST_POINT_TO_PLANE) {
+            n0 = a.nrm[3 * (size_t)b.pos]; n1 = a.nrm[3 * (size_t)b.pos + 1]; n2 = a.nrm[3 * (size_t)b.pos + 2];
+          }
+          accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, cx0, cy0, cz0);
+        }
       }
       fill = 0;
     }
@@ -958,7 +1030,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_pairs_accumulate(PairArgs a) {
     d2 = d2 + dy * dy;
     d2 = d2 + dz * dz;
     b.d2 = d2; b.idx = j; b.pos = (uint32_t)j;
-    accumulate<EST>(acc, x, y, z, b, p, a.nrm, c0[0], c0[1], c0[2]);
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (EST == O3D_EST_POINT_TO_PLANE) {
+      n0 = a.nrm[3 * (size_t)j]; n1 = a.nrm[3 * (size_t)j + 1]; n2 = a.nrm[3 * (size_t)j + 2];
+    }
+    accumulate<EST>(acc, x, y, z, b, p, n0, n1, n2, c0[0], c0[1], c0[2]);
   }
   if (bad) atomicAdd(a.bad, bad);
   block_reduce_store(acc, red, a.partials, blockIdx.x);
@@ -1071,7 +1147,14 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const int gf = O3D_FIX_GRID;
   const int nparts = g + gf;
   const bool tiled = ctx->tile_ok && ctx->use_tile && !ctx->force_generic;
-  if (tiled) hipLaunchKernelGGL(k_icp_search_f32, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  if (tiled) {
+    const int v = ((ctx->tile_stats >> 4) & 3) ^ 2;  // default: unclamped loads + dynamic pruning; debug bits select the others
+    pa.stats &= 15;
+    if (v == 0) hipLaunchKernelGGL(k_icp_search_f32<0>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (v == 1) hipLaunchKernelGGL(k_icp_search_f32<1>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (v == 2) hipLaunchKernelGGL(k_icp_search_f32<2>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else hipLaunchKernelGGL(k_icp_search_f32<3>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  }
   else hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
   if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
   if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
