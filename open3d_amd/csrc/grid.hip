@@ -282,7 +282,10 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     for (;;) {
       double c[3];
       double total = 1.0;
-      for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0;
+      // occupied cells per axis, plus a margin of empty cells: one either side in x, two either side in y and z.  A
+      // query in the outermost y / z layer, or outside the grid, is then at least one cell size (>= the radius) from
+      // every target point, and every other query has all 26 neighbour cells inside the table (no bounds checks).
+      for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0 + (d == 0 ? 2.0 : 4.0);
       total = (c[0] + 2.0) * c[1] * c[2];
       const double budget = std::max(kCellsPerPointBudget * (double)nfinite, 16777216.0);
       if (total < (double)kMaxDenseCells && total <= budget) {
@@ -293,7 +296,8 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     }
     gp.h = h;
     gp.inv_h = 1.0 / h;
-    for (int d = 0; d < 3; d++) gp.gmin[d] = bb[d];
+    for (int d = 0; d < 3; d++) gp.gmin[d] = bb[d] - (d == 0 ? 1.0 : 2.0) * h;
+    gp.margin = 1;
     gp.nxp = gp.nx + 2;
     gp.ncell = (uint32_t)((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz);
   }

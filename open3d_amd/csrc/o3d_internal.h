@@ -23,12 +23,13 @@
 #define O3D_SUM_NC 29
 
 struct GridParams {
-  double gmin[3];  // grid origin (min of finite target points)
+  double gmin[3];  // grid origin (min of the finite target points minus the margin of empty cells)
   double inv_h;    // 1 / cell size
   double h;
   int nx, ny, nz;  // cells per axis (unpadded)
   int nxp;         // padded row length = nx + 2 (one empty cell either side of every x-row)
   uint32_t ncell;  // nxp * ny * nz
+  int margin;      // 1: the outer cell layers (1 in x, 2 in y and z) hold no target point (see o3d_build_target_grid)
 };
 
 // Device-resident ICP state: everything the loop of Registration.cpp:146-167 carries between iterations.
