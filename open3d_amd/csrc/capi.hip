@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -250,8 +251,15 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   int64_t g = (n_src + O3D_BLOCK - 1) / O3D_BLOCK;
   if (g < 1) g = 1;
   if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
-  g = (g + 7) / 8 * 8;  // k_icp_pass maps workgroup -> chunk per XCD (8 XCDs)
+  g = (g + 7) / 8 * 8;  // the pass kernels map workgroup -> chunk per XCD (8 XCDs)
   ctx->pass_grid = (int)g;
+  // k_icp_search_coop holds five workgroups per CU: one resident round of 5 x 256 workgroups, no tail
+  int64_t gs = g < O3D_NUM_CU * 5 ? g : O3D_NUM_CU * 5;
+  if (const char *e = getenv("O3D_SEARCH_GRID")) {  // tuning aid
+    const long v = atol(e);
+    if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
+  }
+  ctx->search_grid = (int)gs;
   const int rows = max_iter + 1;
   if (rows > ctx->log_rows || !ctx->log) {
     if (ctx->log) (void)hipFree(ctx->log);

@@ -582,8 +582,8 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridPa
 // ... whoever owns it.  An item's result is merged into its owner's (best, second-best) pair with LDS atomics; the
 // streaming top-2 rule -- the larger of (incoming, previous best) goes to `second` -- is independent of the order in
 // which the atomics land.  Same verdicts as the per-lane kernel: what is not decisive in fp32 goes to the exact fixup.
-constexpr int kQCap = 384;            // items per wavefront and round (mean demand is ~260; more rounds when it overflows)
-constexpr int kCentreSlot = kMaxRuns; // run-list slot of the centre cell
+constexpr int kQCap = 256;            // items per wavefront and round (mean demand is ~260; more rounds when it overflows)
+constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
 constexpr uint32_t kRunMaxLen = 1u << 28;
 struct CoopWave {
   float4 q[O3D_WAVE];                 // query: position inside its cell, w = bits(padded x cell index)
@@ -661,9 +661,9 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, const uint2 (*runs)
 
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_coop(PassArgs a, GridParams gp) {
+__global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, GridParams gp) {
   if (a.st->done) return;
-  __shared__ uint2 runs[kMaxRuns + 1][O3D_BLOCK];
+  __shared__ uint2 runs[kMaxRuns][O3D_BLOCK];
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
   CoopWave &wl = wls[tid >> 6];
@@ -1376,7 +1376,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   if (tiled) {
     const int v = ((ctx->tile_stats >> 4) & 7) ^ 6;  // default (0): cooperative kernel; debug value 4: per-lane walk with dynamic pruning
     pa.stats &= 15;
-    if ((v & 4) && ctx->gp.margin) hipLaunchKernelGGL(k_icp_search_coop, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    if ((v & 4) && ctx->gp.margin) hipLaunchKernelGGL(k_icp_search_coop, dim3(ctx->search_grid), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     else if (v == 0) hipLaunchKernelGGL(k_icp_search_f32<0>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     else if (v == 1) hipLaunchKernelGGL(k_icp_search_f32<1>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     else if (v == 2) hipLaunchKernelGGL(k_icp_search_f32<2>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);

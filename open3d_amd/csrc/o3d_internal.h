@@ -92,7 +92,8 @@ struct o3d_ctx {
   double *sums = nullptr;      // [32] local
   double *log = nullptr;       // [(max_iter+1)][O3D_LOG_STRIDE]
   int log_rows = 0;
-  int pass_grid = 0;
+  int pass_grid = 0;    // workgroups of the accumulate / per-lane search kernels (one partial row each)
+  int search_grid = 0;  // workgroups of k_icp_search_coop
   int icp_ready = 0;
   int max_iter = 0;
   int enq_passes = 0;
