@@ -253,8 +253,8 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
   g = (g + 7) / 8 * 8;  // the pass kernels map workgroup -> chunk per XCD (8 XCDs)
   ctx->pass_grid = (int)g;
-  // k_icp_search_coop holds five workgroups per CU: one resident round of 5 x 256 workgroups, no tail
-  int64_t gs = g < O3D_NUM_CU * 5 ? g : O3D_NUM_CU * 5;
+  // k_icp_search_coop holds four workgroups per CU: one resident round of 4 x 256 workgroups, no tail
+  int64_t gs = g < O3D_NUM_CU * 4 ? g : O3D_NUM_CU * 4;
   if (const char *e = getenv("O3D_SEARCH_GRID")) {  // tuning aid
     const long v = atol(e);
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;

@@ -143,6 +143,12 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
   }
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per-lane running sums of the next estimate for one accepted correspondence.
 template <int EST>
 __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y, double z, const Best &b,
@@ -341,6 +347,163 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
     c = c_next; pos = pos_next; x = xn; y = yn; z = zn;
   }
   block_reduce_store(acc, red, a.partials, chunk);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same sums on the matrix cores.  Every sum of the estimate is an entry of  S = sum_p v(p) v(p)^T  for a short
+// per-correspondence vector v:
+//   point-to-plane  v = (J0..J5, r, d2, 1):  JTJ = S[0..5][0..5], JTr = S[a][6], sum r^2 = S[6][6], sum d2 = S[7][8], n = S[8][8]
+//   point-to-point  v = (s - c, t - c, 1, d2): sum (s-c) = S[0..2][6], sum (t-c) = S[3..5][6], sum (t-c)(s-c)^T = S[3+a][b],
+//                                              sum |s-c|^2 = S[0][0] + S[1][1] + S[2][2], sum d2 = S[7][6], n = S[6][6]
+// A wavefront stages the 64 vectors of one trip in LDS (component-major) and issues 16 v_mfma_f64_16x16x4_f64, each a
+// rank-4 update with A[i][k] = B[k][i] = v_i(point 4m + k): lane l supplies component l & 15 of point 4m + (l >> 4) for
+// both operands.  The running 16 x 16 fp64 matrix is 4 doubles per lane instead of 30 per-lane accumulators, which is
+// what lets the accumulation ride along in the search kernel (k_icp_search_coop) without costing it its occupancy.
+// fp64 throughout; products are fused into the accumulation (the per-lane form rounds them first), which moves the
+// sums by a few ulp -- far inside the 1e-6 parity bar of the estimate, and the correspondences are not affected.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int kVComp = 9;
+constexpr int kVStride = 68;  // doubles per component row: 64 points + padding that spreads the rows over the LDS banks
+struct VBuf {
+  double v[kVComp][kVStride];
+};
+
+template <int EST>
+__device__ __forceinline__ void make_v(double (&v)[kVComp], bool use, double x, double y, double z, const double4 &p, double n0,
+                                       double n1, double n2, double d2, double cx0, double cy0, double cz0) {
+  if (EST == O3D_EST_POINT_TO_PLANE) {
+    double r = (x - p.x) * n0;
+    r = r + (y - p.y) * n1;
+    r = r + (z - p.z) * n2;
+    v[0] = y * n2 - z * n1;
+    v[1] = z * n0 - x * n2;
+    v[2] = x * n1 - y * n0;
+    v[3] = n0; v[4] = n1; v[5] = n2;
+    v[6] = r; v[7] = d2; v[8] = 1.0;
+  } else {
+    v[0] = x - cx0; v[1] = y - cy0; v[2] = z - cz0;
+    v[3] = p.x - cx0; v[4] = p.y - cy0; v[5] = p.z - cz0;
+    v[6] = 1.0; v[7] = d2; v[8] = 0.0;
+  }
+  if (!use) {
+#pragma unroll
+    for (int c = 0; c < kVComp; c++) v[c] = 0.0;
+  }
+}
+
+// S += sum over the wavefront's 64 lanes of v v^T.  All 64 lanes must call it (lanes without a correspondence bring v = 0).
+__device__ __forceinline__ void mfma_rank64(VBuf &vb, int lane, const double (&v)[kVComp], v4f64 &S) {
+  wave_lds_sync();  // the buffer may alias LDS the wavefront was reading until now
+#pragma unroll
+  for (int c = 0; c < kVComp; c++) vb.v[c][lane] = v[c];
+  wave_lds_sync();
+  const int comp = lane & 15, k = lane >> 4;
+  const double *col = &vb.v[comp < kVComp ? comp : 0][k];
+#pragma unroll
+  for (int m = 0; m < 16; m++) {
+    double a = col[4 * m];
+    if (comp >= kVComp) a = 0.0;
+    S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, S, 0, 0, 0);
+  }
+  wave_lds_sync();
+}
+
+// Entry (row, col) of S that sum k of the partial row comes from (k < 30); point-to-point sum 15 is the trace term.
+template <int EST>
+__device__ __forceinline__ void sum_source(int k, int &row, int &col) {
+  row = 15; col = 15;  // an entry that is always zero
+  if (EST == O3D_EST_POINT_TO_PLANE) {
+    if (k < 21) {
+      int a = 0, rem = k;
+      while (rem >= 6 - a) { rem -= 6 - a; a++; }
+      row = a; col = a + rem;
+    } else if (k < 27) { row = k - 21; col = 6; }
+    else if (k == 27) { row = 6; col = 6; }
+    else if (k == O3D_SUM_D2) { row = 7; col = 8; }
+    else if (k == O3D_SUM_NC) { row = 8; col = 8; }
+  } else {
+    if (k < 6) { row = k; col = 6; }
+    else if (k < 15) { row = 3 + (k - 6) / 3; col = (k - 6) % 3; }
+    else if (k == O3D_SUM_D2) { row = 7; col = 6; }
+    else if (k == O3D_SUM_NC) { row = 6; col = 6; }
+  }
+}
+
+// Combine the workgroup's wavefronts in a fixed order and write one 32-double partial row.
+// C/D map of v_mfma_f64_16x16x4_f64: register r of lane l holds S[(l >> 4) + 4 r][l & 15].
+template <int EST>
+__device__ __forceinline__ void mfma_reduce_store(const v4f64 &S, double (*red)[16][16], double *__restrict__ partials, unsigned chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[wave][(lane >> 4) + 4 * r][lane & 15] = S[r];
+  __syncthreads();
+  if (threadIdx.x < O3D_NSUMS) {
+    const int k = threadIdx.x;
+    double v = 0.0;
+    if (k < 30) {
+      int row, col;
+      sum_source<EST>(k, row, col);
+      v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+      if (EST == O3D_EST_POINT_TO_POINT && k == 15) {
+        v = 0.0;
+        for (int d = 0; d < 3; d++) v += ((red[0][d][d] + red[1][d][d]) + red[2][d][d]) + red[3][d][d];
+      }
+    }
+    partials[(size_t)chunk * O3D_NSUMS + k] = v;
+  }
+}
+
+// k_icp_accumulate with the sums on the matrix cores (same reads, same confirmation of the fp32 candidates).
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
+  if (a.st->done) return;
+  // the staging buffers and the final cross-wavefront combine share LDS (the combine starts after the last trip)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
+  static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
+  VBuf *vbs = reinterpret_cast<VBuf *>(lds_raw);
+  double (*red)[16][16] = reinterpret_cast<double (*)[16][16]>(lds_raw);
+  const int lane = threadIdx.x & 63;
+  VBuf &vb = vbs[threadIdx.x >> 6];
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  v4f64 S = {0.0, 0.0, 0.0, 0.0};
+  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
+  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t beg = (int64_t)chunk * per;
+  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+  for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform: every wavefront runs every trip
+    const int64_t i = base + threadIdx.x;
+    int32_t c = O3D_CORR_NONE;
+    if (i < end) c = a.corr[i];
+    bool use = c >= 0 || c == O3D_CORR_CANDIDATE;
+    double x = 0.0, y = 0.0, z = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, d2 = 0.0;
+    double4 p = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (use) {
+      const uint32_t pos = a.pos[i];
+      x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
+      p = a.tgt[pos];
+      if (EST == O3D_EST_POINT_TO_PLANE) {
+        n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
+      }
+      const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+      d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (c == O3D_CORR_CANDIDATE) {
+        if (d2 < a.thr) {
+          a.corr[i] = (int32_t)__double_as_longlong(p.w);
+        } else {
+          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the fp32 error bound; stay exact regardless
+          atomicOr(&a.pend[i >> 6], 1ull << (i & 63));
+          use = false;
+        }
+      }
+    }
+    double v[kVComp];
+    make_v<EST>(v, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0);
+    mfma_rank64(vb, lane, v, S);
+  }
+  __syncthreads();  // every wavefront is done with its staging buffer
+  mfma_reduce_store<EST>(S, red, a.partials, chunk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -586,17 +749,15 @@ constexpr int kQCap = 256;            // items per wavefront and round (mean dem
 constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
 constexpr uint32_t kRunMaxLen = 1u << 28;
 struct CoopWave {
+  union {
+    uint2 runs[kMaxRuns][O3D_WAVE];   // [slot][lane]: the lane's run list (phase 1: slot 0 = centre cell)
+    VBuf vb;                          // after the search: staging of the estimate's vectors for the matrix cores
+  };
   float4 q[O3D_WAVE];                 // query: position inside its cell, w = bits(padded x cell index)
   unsigned long long best[O3D_WAVE];  // bits(d2) << 32 | position in tgt_local
   uint32_t second[O3D_WAVE];          // bits(second-best d2)
   uint32_t items[kQCap];              // owner lane | run slot << 6 | chunk index << 10
 };
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // A run of candidates: x = first position in tgt_local, y = length << 4 | (dy + 1) | (dz + 1) << 2.
 __device__ __forceinline__ uint2 make_run(uint32_t s, uint32_t e, int dy, int dz) {
@@ -604,9 +765,8 @@ __device__ __forceinline__ uint2 make_run(uint32_t s, uint32_t e, int dy, int dz
 }
 
 // One phase: every lane brings runs in consecutive slots of its LDS column starting at `first`, `tot` items in all.
-__device__ __forceinline__ unsigned coop_phase(CoopWave &wl, const uint2 (*runs)[O3D_BLOCK], int wave0, int lane, int first,
-                                               uint32_t tot, const float4 *__restrict__ tl, float hf) {
-  const int col = wave0 + lane;
+__device__ __forceinline__ unsigned coop_phase(CoopWave &wl, int lane, int first, uint32_t tot, const float4 *__restrict__ tl,
+                                               float hf) {
   int li = first - 1;
   uint32_t ch = 0, nch = 0;
   unsigned trips = 0;
@@ -626,7 +786,7 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, const uint2 (*runs)
       if (ch >= nch) {
         li++;
         ch = 0;
-        nch = ((runs[li][col].y >> 4) + 3u) >> 2;
+        nch = ((wl.runs[li][lane].y >> 4) + 3u) >> 2;
       }
       wl.items[k] = (uint32_t)lane | ((uint32_t)li << 6) | (ch << 10);
       ch++;
@@ -639,7 +799,7 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, const uint2 (*runs)
       if (t < nitems) {
         const uint32_t it = wl.items[t];
         const int owner = it & 63;
-        const uint2 run = runs[(it >> 6) & 15][wave0 + owner];
+        const uint2 run = wl.runs[(it >> 6) & 15][owner];
         const uint32_t e = run.x + (run.y >> 4);
         const uint32_t j = run.x + ((it >> 10) << 2);
         const float4 q = wl.q[owner];
@@ -661,12 +821,15 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, const uint2 (*runs)
 
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
-__global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, GridParams gp) {
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
   if (a.st->done) return;
-  __shared__ uint2 runs[kMaxRuns][O3D_BLOCK];
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
   const int tid = threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
   CoopWave &wl = wls[tid >> 6];
+  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  v4f64 S = {0.0, 0.0, 0.0, 0.0};
   const int apply = a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
@@ -683,16 +846,45 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
   const unsigned long long kBestInit = (unsigned long long)0x7F800000u << 32;  // +inf, position 0
   const int row_y = gp.nxp, row_z = gp.ny * gp.nxp;  // table strides of one cell in y / z (wave-uniform)
 
+  // The fp32 winner is confirmed in fp64 with the arithmetic of the exact search (it then IS the exact result: every
+  // other candidate is farther by more than the fp32 error bound), and its terms of the next estimate go to the matrix
+  // cores.  What is not decisive in fp32 is left to k_icp_fixup.  The gathers of the matched target point and normal
+  // are issued at the end of a trip and consumed in the next one, behind that trip's own source loads, so that their
+  // latency is not exposed.
+  bool use_p = false;  // carried from the previous trip
+  int64_t i_p = 0;
+  double4 p_p = make_double4(0.0, 0.0, 0.0, 0.0);
+  double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0;
+  auto consume = [&]() {
+    double d2 = 0.0;
+    if (use_p) {
+      const double ddx = xs - p_p.x, ddy = ys - p_p.y, ddz = zs - p_p.z;
+      d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (d2 < a.thr) {
+        a.corr[i_p] = (int32_t)__double_as_longlong(p_p.w);
+      } else {  // cannot happen within the fp32 error bound; stay exact regardless
+        a.corr[i_p] = O3D_CORR_PENDING;
+        atomicOr(&a.pend[i_p >> 6], 1ull << (i_p & 63));
+        use_p = false;
+      }
+    }
+    double v[kVComp];
+    make_v<EST>(v, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0);
+    mfma_rank64(wl.vb, lane, v, S);  // begins and ends with a wavefront LDS sync
+  };
+
   for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
     const int64_t i = base + tid;
     const bool valid = i < end;
     double x = 0, y = 0, z = 0;
     if (valid) {
       x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
-      if (apply) {
-        apply_update(T, w, x, y, z);
-        a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
-      }
+    }
+    if (valid && apply) {
+      apply_update(T, w, x, y, z);
+      a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
     }
     const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
     const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
@@ -710,21 +902,22 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
       const CellQuad qc = *reinterpret_cast<const CellQuad *>(rowp);
       s0 = qc.v[0]; s1 = qc.v[1]; s2 = qc.v[2]; s3 = qc.v[3];
     }
+    if (base != beg) consume();  // the previous trip's matches, behind this trip's source and table loads
     bool too_long = s3 - s0 >= kRunMaxLen;
     // phase 1: the centre cells of the wavefront's queries
     wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(cx + 1));
     wl.best[lane] = kBestInit;
     wl.second[lane] = 0x7F800000u;
-    runs[kCentreSlot][tid] = make_run(s1, too_long ? s1 : s2, 0, 0);
+    wl.runs[kCentreSlot][lane] = make_run(s1, too_long ? s1 : s2, 0, 0);
     wave_lds_sync();
-    unsigned trips = coop_phase(wl, runs, wave0, lane, kCentreSlot, too_long ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
+    unsigned trips = coop_phase(wl, lane, kCentreSlot, too_long ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
+    const float best1 = __uint_as_float((uint32_t)(wl.best[lane] >> 32));
     // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
     // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
     // together), instead of eight loads per query up front.
     int nruns = 0;
     uint32_t tot = 0;
     if (inside && !too_long) {
-      const float best1 = __uint_as_float((uint32_t)(wl.best[lane] >> 32));
       float t;
       t = fmaxf(qx - margin, 0.f); const float axm = t * t;
       t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
@@ -742,8 +935,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
         const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
         if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
       }
-      if (axm <= reach && s0 < s1) { runs[nruns][tid] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
-      if (axp <= reach && s2 < s3) { runs[nruns][tid] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
+      if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
+      if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
 #pragma unroll
       for (int r = 0; r < 9; r++) {
         if (r == 4) continue;
@@ -754,7 +947,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
         const uint32_t e = (axp + byz <= reach) ? rowq[r].v[3] : rowq[r].v[2];
         if (s < e) {
           too_long = too_long || e - s >= kRunMaxLen;
-          runs[nruns][tid] = make_run(s, e, dy, dz);
+          wl.runs[nruns][lane] = make_run(s, e, dy, dz);
           tot += (e - s + 3u) >> 2;
           nruns++;
         }
@@ -762,7 +955,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
       if (too_long) tot = 0;
     }
     wave_lds_sync();
-    trips += coop_phase(wl, runs, wave0, lane, 0, tot, tl, hf);
+    trips += coop_phase(wl, lane, 0, tot, tl, hf);
     uint32_t bpos = 0;
     if (inside) {
       const unsigned long long bb = wl.best[lane];
@@ -772,6 +965,16 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
       const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
       if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
       else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
+    }
+    // issue the gathers for this trip's candidates; they are consumed in the next trip (or after the loop)
+    use_p = verdict == O3D_CORR_CANDIDATE;
+    i_p = i;
+    xs = x; ys = y; zs = z;
+    if (use_p) {
+      p_p = a.tgt[bpos];
+      if (EST == O3D_EST_POINT_TO_PLANE) {
+        n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
+      }
     }
     if (a.stats) {
       const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
@@ -791,13 +994,16 @@ __global__ __launch_bounds__(O3D_BLOCK, 5) void k_icp_search_coop(PassArgs a, Gr
       }
     }
     if (valid) {
-      a.corr[i] = verdict;
+      if (!use_p) a.corr[i] = verdict;  // a candidate's entry is written when it is confirmed
       a.pos[i] = bpos;
     }
     const unsigned long long pm = __ballot(verdict == O3D_CORR_PENDING);
     if (lane == 0 && base + wave0 < end) a.pend[(base + wave0) >> 6] = pm;
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
+  if (beg < end) consume();
+  __syncthreads();
+  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, chunk);
 }
 
 // Exact per-lane fp64 search for the points the fp32 prefilter search left undecided (corr == -2).  Each workgroup walks a
@@ -1371,26 +1577,41 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.pos = ctx->pos_sorted;
   pa.pend = ctx->pend_mask;
   const int gf = O3D_FIX_GRID;
-  const int nparts = g + gf;
   const bool tiled = ctx->tile_ok && ctx->use_tile && !ctx->force_generic;
-  if (tiled) {
-    const int v = ((ctx->tile_stats >> 4) & 7) ^ 6;  // default (0): cooperative kernel; debug value 4: per-lane walk with dynamic pruning
+  // default: cooperative search with the accumulation fused in (no separate accumulate kernel); debug bits of the
+  // stats flag select the per-lane search kernels (16..48, 64) and the per-lane accumulate kernel (128)
+  const int v = ((ctx->tile_stats >> 4) & 7) ^ 6;
+  const bool fused = tiled && (v & 4) && ctx->gp.margin;
+  const int grows = fused ? ctx->search_grid : g;  // partial rows written ahead of the fixup rows
+  const int nparts = grows + gf;
+  if (fused) {
     pa.stats &= 15;
-    if ((v & 4) && ctx->gp.margin) hipLaunchKernelGGL(k_icp_search_coop, dim3(ctx->search_grid), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else if (v == 0) hipLaunchKernelGGL(k_icp_search_f32<0>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else if (v == 1) hipLaunchKernelGGL(k_icp_search_f32<1>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else if (v == 2) hipLaunchKernelGGL(k_icp_search_f32<2>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    if (p2l) hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_PLANE>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_POINT>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  } else if (tiled) {
+    pa.stats &= 15;
+    if ((v & 3) == 0) hipLaunchKernelGGL(k_icp_search_f32<0>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if ((v & 3) == 1) hipLaunchKernelGGL(k_icp_search_f32<1>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if ((v & 3) == 2) hipLaunchKernelGGL(k_icp_search_f32<2>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     else hipLaunchKernelGGL(k_icp_search_f32<3>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-  }
-  else hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-  if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-  if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-  else hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-  if (tiled) {
-    if (p2l) hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
-    else hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, g);
   } else {
-    O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)g * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
+    hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  }
+  if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
+  if (!fused) {
+    if (ctx->tile_stats & 128) {  // debug: per-lane accumulators
+      if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+      else hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+    } else {
+      if (p2l) hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+      else hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+    }
+  }
+  if (tiled) {
+    if (p2l) hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
+    else hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
+  } else {
+    O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)grows * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 2], ctx->stream));
