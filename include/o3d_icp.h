@@ -171,17 +171,18 @@ O3D_API int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_transformation[16],
 /* Per-pass history for parity tests: row p = {fitness, rmse, n_corr, sum_d2, T[16] colmajor, sums[32]} = 52 doubles. */
 #define O3D_LOG_STRIDE 52
 O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows);
-/* HIP-event timing of the dominant kernel (k_icp_pass) on the context's stream.  enable != 0: every following pass is
- * bracketed by HIP events (at most 340 passes are kept).  o3d_icp_profile_read synchronises, returns the mean kernel
- * duration in milliseconds over the recorded passes and their number, and clears the record. */
+/* HIP-event timing of the pass kernels on the context's stream.  enable != 0: every following pass is bracketed by HIP
+ * events (at most 340 passes are kept).  o3d_icp_profile_read synchronises, returns the mean duration in milliseconds
+ * of search + accumulation + fixup over the recorded passes and their number, and clears the record. */
 O3D_API int o3d_icp_profile(o3d_ctx *ctx, int enable);
 O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count);
-/* Same, split: out_mean_ms[0] = search kernel (k_icp_search / k_icp_search_tile), [1] = k_icp_accumulate (+ k_icp_fixup). */
+/* Same, split: out_mean_ms[0] = k_icp_search_coop (search with the estimate's sums fused in; k_icp_search on the
+ * alternative path), [1] = k_icp_fixup (alternative path: k_icp_accumulate_mfma). */
 O3D_API int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count);
-/* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 search kernel instead
- * of the default fp32-prefilter search (both give the exact result); collect_tile_stats != 0 makes the fp32 search count
- * {wave-iterations, -, surviving runs, points left to the exact fixup, -, valid lanes} (process-wide counters, read by
- * o3d_debug_tile_stats). */
+/* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 search kernel +
+ * accumulation kernel instead of the default cooperative fp32-prefilter search (both give the exact result);
+ * collect_tile_stats != 0 makes the cooperative search count {wave trips, dense item trips, runs listed, points left to
+ * the exact fixup, items, valid lanes} (process-wide counters, read by o3d_debug_tile_stats). */
 O3D_API int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats);
 O3D_API int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset);
 /* Processing order of the source shard after o3d_icp_setup: out[p] = caller's index of the p-th processed point. */

@@ -156,7 +156,8 @@ class Context:
         self.check(self._lib.o3d_ctx_use_own_stream(self._h))
 
     def debug_set(self, use_tile_search=True, collect_tile_stats=False):
-        """use_tile_search=False: run the per-lane fp64 search kernel instead of the default fp32-prefilter search."""
+        """use_tile_search=False: run the per-lane fp64 search + accumulation kernels instead of the default cooperative
+        fp32-prefilter search."""
         self.check(self._lib.o3d_debug_set(self._h, 0 if use_tile_search else 1, int(collect_tile_stats)))
 
     def source_perm(self, n_src):
@@ -167,8 +168,7 @@ class Context:
     def tile_stats(self, reset=True):
         out = (C.c_uint64 * 8)()
         self.check(self._lib.o3d_debug_tile_stats(self._h, out, int(reset)))
-        keys = ["wave_iters", "walk_trips_wave", "candidates", "exact_lanes", "walk_trips_lane", "valid_lanes",
-                "centre_trips_wave", "centre_trips_lane"]
+        keys = ["wave_iters", "item_trips", "runs", "exact_lanes", "items", "valid_lanes", "_6", "_7"]
         return dict(zip(keys, [int(v) for v in out]))
 
     @property

@@ -322,7 +322,6 @@ int o3d_icp_step(o3d_ctx *ctx) {
 
 int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
-  ctx->force_generic = force_generic_pass & 1;
   ctx->use_tile = force_generic_pass ? 0 : 1;
   ctx->tile_stats = collect_tile_stats;
   return O3D_OK;
@@ -498,7 +497,6 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   auto work = [&](int wi) {
     o3d_ctx *w = ctx->workers[(size_t)wi];
     w->use_tile = ctx->use_tile;
-    w->force_generic = ctx->force_generic;
     for (;;) {
       const int64_t p = next.fetch_add(1);
       if (p >= n_pairs) break;

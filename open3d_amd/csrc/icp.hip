@@ -202,9 +202,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
   }
 }
 
-// Optional counters of the fp32 search (tests and tuning): [0] wave-iterations, [1] walk trips (wave level), [2] runs
-// listed, [3] lanes left to the exact fixup, [4] walk trips (lane level), [5] valid lanes, [6] centre-cell trips (wave
-// level: the maximum over lanes), [7] centre-cell trips (lane level).
+// Optional counters of the cooperative search (tests and tuning): [0] wave trips, [1] dense item trips, [2] runs
+// listed, [3] lanes left to the exact fixup, [4] items (four candidates each), [5] valid lanes.
 __device__ unsigned long long g_tile_stats[8];
 
 struct PassArgs {
@@ -277,76 +276,6 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams
     a.corr[i] = (int32_t)b.idx;
     a.pos[i] = b.pos;
   }
-}
-
-// Accumulation pass: streams the source with its correspondences, gathers the matched target point (and normal) by
-// position, and reduces the sums of the next estimate -- utility::ComputeJTJandJTr (utility/Eigen.cpp:159-201) with the
-// point-to-plane rows of TransformationEstimation.cpp:79-86, or the Umeyama moments of :53-59 -- per lane in fp64, then
-// by wavefront shuffles and an LDS tree to one 32-double partial row per chunk.  A candidate proposed by the tile pass
-// (corr == -3) is confirmed here in fp64 with the arithmetic of the exact search; if it fails it is left to k_icp_fixup.
-template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate(PassArgs a) {
-  if (a.st->done) return;
-  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
-  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
-  double acc[30];
-#pragma unroll
-  for (int k = 0; k < 30; k++) acc[k] = 0.0;
-  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
-  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int64_t beg = (int64_t)chunk * per;
-  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-  // Software pipeline: the streamed reads of the next point (corr, pos, xyz: independent of everything) are issued
-  // together with the dependent gathers of the current one (target point and normal at pos), so that one memory
-  // latency per point is exposed instead of two.
-  int64_t i = beg + threadIdx.x;
-  int32_t c = O3D_CORR_NONE;
-  uint32_t pos = 0;
-  double x = 0.0, y = 0.0, z = 0.0;
-  if (i < end) {
-    c = a.corr[i]; pos = a.pos[i];
-    x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
-  }
-  for (; i < end; i += O3D_BLOCK) {
-    const bool use = c >= 0 || c == O3D_CORR_CANDIDATE;
-    double4 p = make_double4(0.0, 0.0, 0.0, 0.0);
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-    if (use) {
-      p = a.tgt[pos];
-      if (EST == O3D_EST_POINT_TO_PLANE) {
-        n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
-      }
-    }
-    const int64_t in = i + O3D_BLOCK;
-    int32_t c_next = O3D_CORR_NONE;
-    uint32_t pos_next = 0;
-    double xn = 0.0, yn = 0.0, zn = 0.0;
-    if (in < end) {
-      c_next = a.corr[in]; pos_next = a.pos[in];
-      xn = a.src[3 * in]; yn = a.src[3 * in + 1]; zn = a.src[3 * in + 2];
-    }
-    if (use) {
-      Best b;
-      const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
-      double d2 = ddx * ddx;
-      d2 = d2 + ddy * ddy;
-      d2 = d2 + ddz * ddz;
-      b.d2 = d2; b.idx = __double_as_longlong(p.w); b.pos = pos;
-      bool ok = true;
-      if (c == O3D_CORR_CANDIDATE) {
-        if (d2 < a.thr) {
-          a.corr[i] = (int32_t)b.idx;
-        } else {
-          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the fp32 error bound; stay exact regardless
-          atomicOr(&a.pend[i >> 6], 1ull << (i & 63));
-          ok = false;
-        }
-      }
-      if (ok) accumulate<EST>(acc, x, y, z, b, p, n0, n1, n2, cx0, cy0, cz0);
-    }
-    c = c_next; pos = pos_next; x = xn; y = yn; z = zn;
-  }
-  block_reduce_store(acc, red, a.partials, chunk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -540,17 +469,10 @@ struct F32State {
 // Up to four candidates of tgt_local[j, e): one address, four 16-byte loads at immediate offsets.  Slots past the end
 // read the next cell's points (the array carries four entries of padding) and are neutralised (d2 = +inf), so that
 // `second` never sees them.  qy / qz are relative to the origin of the run's row (the caller shifts them per run).
-template <int V>
 __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_t j, uint32_t e, float qx, float qy, float qz,
                                           int cxp, float hf, F32State &st) {
   const float4 *__restrict__ p = tl + j;
-  float4 c[4];
-  if (V & 1) {
-    const uint32_t last = e - 1;
-    c[0] = tl[j]; c[1] = tl[min(j + 1, last)]; c[2] = tl[min(j + 2, last)]; c[3] = tl[min(j + 3, last)];
-  } else {
-    c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
-  }
+  const float4 c[4] = {p[0], p[1], p[2], p[3]};
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const float dx = qx - (c[u].x + (float)(__float_as_int(c[u].w) - cxp) * hf);
@@ -561,179 +483,6 @@ __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_
     st.second = fminf(st.second, fmaxf(d2, st.best));
     st.bpos = d2 < st.best ? j + u : st.bpos;
     st.best = fminf(st.best, d2);
-  }
-}
-
-template <int V>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_search_f32(PassArgs a, GridParams gp) {
-  if (a.st->done) return;
-  __shared__ uint32_t run_s[kMaxRuns][O3D_BLOCK];
-  __shared__ uint32_t run_e[kMaxRuns][O3D_BLOCK];
-  __shared__ unsigned char run_code[kMaxRuns][O3D_BLOCK];  // (dy + 1) + 3 * (dz + 1)
-  __shared__ float run_b[kMaxRuns][O3D_BLOCK];             // squared face distance of the run: re-checked when it is reached
-  const int tid = threadIdx.x;
-  const int apply = a.st->apply_update;
-  double T[12], w[4];
-  load_update(a.st, T, w);
-  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
-  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int64_t beg = (int64_t)chunk * per;
-  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-  const float hf = (float)gp.h;
-  const float err = kF32Err * hf * hf;
-  const float thrf = (float)a.thr;
-  const float margin = 1e-5f * hf;
-  const float4 *__restrict__ tl = a.tgt_local;
-  const uint32_t *__restrict__ cs = a.cell_start;
-
-  for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
-    const int64_t i = base + tid;
-    const bool valid = i < end;
-    double x = 0, y = 0, z = 0;
-    if (valid) {
-      x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
-      if (apply) {
-        apply_update(T, w, x, y, z);
-        a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
-      }
-    }
-    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
-    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
-    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
-    const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
-    int32_t verdict = valid && !inside ? O3D_CORR_PENDING : O3D_CORR_NONE;
-    F32State st;
-    st.best = INFINITY; st.second = INFINITY; st.bpos = 0;
-    int nruns = 0;
-    unsigned wtrips = 0, ltrips = 0, ctrips = 0;  // statistics only
-    float qx = 0, qy = 0, qz = 0;
-    const int cxp = cx + 1;  // padded x index of the query's cell
-    if (inside) {
-      // position inside the query's cell (fp64, then rounded once)
-      qx = (float)((x - gp.gmin[0]) - (double)cx * gp.h);
-      qy = (float)((y - gp.gmin[1]) - (double)cy * gp.h);
-      qz = (float)((z - gp.gmin[2]) - (double)cz * gp.h);
-      const uint32_t rowc = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx;
-      const CellQuad qc = *reinterpret_cast<const CellQuad *>(cs + rowc);
-      const uint32_t s0 = qc.v[0], s1 = qc.v[1], s2 = qc.v[2], s3 = qc.v[3];
-      // the eight neighbouring rows, slot r = (dy + 1) + 3 * (dz + 1) (rows outside the grid read a clamped, valid
-      // address); fully unrolled with static slots so that the table stays in registers
-      uint32_t q0[9], q1[9], q2[9], q3[9];
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        if (r == 4) continue;
-        const int dy = r % 3 - 1, dz = r / 3 - 1;
-        const int zz = min(max(cz + dz, 0), gp.nz - 1), yy = min(max(cy + dy, 0), gp.ny - 1);
-        const uint32_t rr = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp + (uint32_t)cx;
-        const CellQuad t4 = *reinterpret_cast<const CellQuad *>(cs + rr);
-        q0[r] = t4.v[0]; q1[r] = t4.v[1]; q2[r] = t4.v[2]; q3[r] = t4.v[3];
-      }
-      // centre cell first
-      for (uint32_t j = s1; j < s2; j += 4) scan4_f32<V>(tl, j, s2, qx, qy, qz, cxp, hf, st);
-      ctrips = (s2 - s1 + 3) >> 2;
-      // conservative squared face distances (fp32, shrunk by a margin that dominates the rounding)
-      float t;
-      t = fmaxf(qx - margin, 0.f); const float axm = t * t;
-      t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
-      t = fmaxf(qy - margin, 0.f); const float aym = t * t;
-      t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
-      t = fmaxf(qz - margin, 0.f); const float azm = t * t;
-      t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
-      const float reach = fminf(st.best, thrf + err) + 4.0f * err;
-      if (axm <= reach && s0 < s1) { run_s[nruns][tid] = s0; run_e[nruns][tid] = s1; run_code[nruns][tid] = 4; run_b[nruns][tid] = axm; nruns++; }
-      if (axp <= reach && s2 < s3) { run_s[nruns][tid] = s2; run_e[nruns][tid] = s3; run_code[nruns][tid] = 4; run_b[nruns][tid] = axp; nruns++; }
-      // face neighbours before edge neighbours: a lane that starts with a poor bound (empty centre cell) tightens it on
-      // the nearest rows and skips the others when it reaches them
-      constexpr int kRowOrder[8] = {3, 5, 1, 7, 0, 2, 6, 8};
-#pragma unroll
-      for (int ro = 0; ro < 8; ro++) {
-        const int r = kRowOrder[ro];
-        const int dy = r % 3 - 1, dz = r / 3 - 1;
-        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
-        const int zz = cz + dz, yy = cy + dy;
-        if (byz <= reach && zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny) {
-          const uint32_t s = (axm + byz <= reach) ? q0[r] : q1[r];  // corner reach: widen the run to the left cell
-          const uint32_t e = (axp + byz <= reach) ? q3[r] : q2[r];  // ... and to the right cell
-          if (s < e) {
-            run_s[nruns][tid] = s; run_e[nruns][tid] = e;
-            run_code[nruns][tid] = (unsigned char)r;
-            run_b[nruns][tid] = byz;
-            nruns++;
-          }
-        }
-      }
-    }
-    // flattened walk over the lane's surviving runs (LDS columns are lane-private: no barrier needed).  A run is
-    // re-checked against the bound the lane has reached by then and dropped if it can no longer matter.
-    {
-      int li = 0;
-      uint32_t j = 0, e = 0;
-      float qyr = 0.f, qzr = 0.f;
-      bool more = nruns > 0;
-      while (__any(more)) {
-        wtrips++;
-        if (more) {
-#pragma unroll
-          for (int attempt = 0; attempt < 2; attempt++) {
-            if (j >= e && li < nruns) {
-              const float b = run_b[li][tid];
-              j = run_s[li][tid]; e = run_e[li][tid];
-              const int code = run_code[li][tid];
-              li++;
-              if ((V & 2) && b > fminf(st.best, thrf + err) + 4.0f * err) e = j;  // cannot matter any more
-              qyr = qy - (float)(code % 3 - 1) * hf; qzr = qz - (float)(code / 3 - 1) * hf;
-            }
-          }
-          if (j < e) {
-            ltrips++;
-            scan4_f32<V>(tl, j, e, qx, qyr, qzr, cxp, hf, st);
-            j += 4;
-          }
-          more = (j < e) || (li < nruns);
-        }
-      }
-    }
-    if (inside) {
-      const bool near_tie = (st.second - st.best) <= 2.0f * err;  // inf - inf = NaN -> false
-      const bool near_thr = fabsf(st.best - thrf) <= err + 1e-6f * thrf;
-      if (st.best <= thrf + err && (near_tie || near_thr)) verdict = O3D_CORR_PENDING;
-      else if (st.best < thrf) verdict = O3D_CORR_CANDIDATE;
-    }
-    if (a.stats & 8) {  // histogram of per-lane trips (centre + walk): bins <=2, 3-4, 5-6, 7-8, 9-12, >12; [6] = waves, [7] = sum of wave max
-      const unsigned t = ltrips + ctrips;
-      const int bin = t <= 2 ? 0 : (t <= 4 ? 1 : (t <= 6 ? 2 : (t <= 8 ? 3 : (t <= 12 ? 4 : 5))));
-      if (valid) atomicAdd(&g_tile_stats[bin], 1ull);
-      unsigned m = t;
-      for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d, O3D_WAVE));
-      if ((tid & 63) == 0) { atomicAdd(&g_tile_stats[6], 1ull); atomicAdd(&g_tile_stats[7], (unsigned long long)m); }
-    } else if (a.stats) {
-      const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
-      unsigned long long rsum = (unsigned long long)nruns, lsum = ltrips, csum = ctrips;
-      unsigned cmax = ctrips;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        rsum += __shfl_xor(rsum, d, O3D_WAVE);
-        lsum += __shfl_xor(lsum, d, O3D_WAVE);
-        csum += __shfl_xor(csum, d, O3D_WAVE);
-        cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, d, O3D_WAVE));
-      }
-      if ((tid & 63) == 0) {
-        atomicAdd(&g_tile_stats[0], 1ull);
-        atomicAdd(&g_tile_stats[1], (unsigned long long)wtrips);
-        atomicAdd(&g_tile_stats[2], rsum);
-        atomicAdd(&g_tile_stats[3], np);
-        atomicAdd(&g_tile_stats[4], lsum);
-        atomicAdd(&g_tile_stats[5], nv);
-        atomicAdd(&g_tile_stats[6], (unsigned long long)cmax);
-        atomicAdd(&g_tile_stats[7], csum);
-      }
-    }
-    if (valid) {
-      a.corr[i] = verdict;
-      a.pos[i] = st.bpos;
-    }
-    const unsigned long long pm = __ballot(verdict == O3D_CORR_PENDING);
-    if ((tid & 63) == 0 && base + (tid & ~63) < end) a.pend[(base + (tid & ~63)) >> 6] = pm;
   }
 }
 
@@ -806,7 +555,7 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, int lane, int first
         const float qyr = q.y - (float)((int)(run.y & 3u) - 1) * hf, qzr = q.z - (float)((int)((run.y >> 2) & 3u) - 1) * hf;
         F32State st;
         st.best = INFINITY; st.second = INFINITY; st.bpos = j;
-        scan4_f32<0>(tl, j, e, q.x, qyr, qzr, __float_as_int(q.w), hf, st);
+        scan4_f32(tl, j, e, q.x, qyr, qzr, __float_as_int(q.w), hf, st);
         const unsigned long long v = ((unsigned long long)__float_as_uint(st.best) << 32) | st.bpos;
         const unsigned long long old = atomicMin(&wl.best[owner], v);
         const unsigned long long disp = old > v ? old : v;
@@ -1561,9 +1310,8 @@ int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]) {
 }
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
-  const int g = ctx->pass_grid;
   const bool prof = ctx->prof_on && ctx->prof_n < 340;
-  if (prof) {  // three events per pass: before the search, after it, after accumulate (+ fixup)
+  if (prof) {  // three events per pass: before the search, after it, after the fixup
     for (int k = 0; k < 3; k++)
       if (!ctx->prof_ev[3 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[3 * ctx->prof_n + k]));
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n], ctx->stream));
@@ -1573,44 +1321,27 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.src = ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
-  const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
   pa.pos = ctx->pos_sorted;
   pa.pend = ctx->pend_mask;
+  const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
   const int gf = O3D_FIX_GRID;
-  const bool tiled = ctx->tile_ok && ctx->use_tile && !ctx->force_generic;
-  // default: cooperative search with the accumulation fused in (no separate accumulate kernel); debug bits of the
-  // stats flag select the per-lane search kernels (16..48, 64) and the per-lane accumulate kernel (128)
-  const int v = ((ctx->tile_stats >> 4) & 7) ^ 6;
-  const bool fused = tiled && (v & 4) && ctx->gp.margin;
-  const int grows = fused ? ctx->search_grid : g;  // partial rows written ahead of the fixup rows
+  // Default: the cooperative fp32-prefilter search with the estimate's sums fused in, then the exact fixup of what it
+  // left undecided.  Alternative (grids too large for the fp32 error bound, or forced by o3d_debug_set): the per-lane
+  // fp64 search followed by the accumulation kernel.  Either way one partial row per workgroup, fixup rows behind.
+  const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
+  const int grows = fused ? ctx->search_grid : ctx->pass_grid;
   const int nparts = grows + gf;
   if (fused) {
-    pa.stats &= 15;
     if (p2l) hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_PLANE>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     else hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_POINT>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-  } else if (tiled) {
-    pa.stats &= 15;
-    if ((v & 3) == 0) hipLaunchKernelGGL(k_icp_search_f32<0>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else if ((v & 3) == 1) hipLaunchKernelGGL(k_icp_search_f32<1>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else if ((v & 3) == 2) hipLaunchKernelGGL(k_icp_search_f32<2>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else hipLaunchKernelGGL(k_icp_search_f32<3>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-  } else {
-    hipLaunchKernelGGL(k_icp_search, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-  }
-  if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-  if (!fused) {
-    if (ctx->tile_stats & 128) {  // debug: per-lane accumulators
-      if (p2l) hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-      else hipLaunchKernelGGL(k_icp_accumulate<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-    } else {
-      if (p2l) hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_PLANE>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-      else hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_POINT>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-    }
-  }
-  if (tiled) {
+    if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
     if (p2l) hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
     else hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
   } else {
+    hipLaunchKernelGGL(k_icp_search, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
+    if (p2l) hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_PLANE>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+    else hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_POINT>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa);
     O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)grows * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {

@@ -50,10 +50,6 @@ struct IcpState {
   int pad;
 };
 
-struct Timer {
-  hipEvent_t a = nullptr, b = nullptr;
-};
-
 struct o3d_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -69,9 +65,8 @@ struct o3d_ctx {
   float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
   size_t cap_local = 0;
   int tile_ok = 0;                // fp32 prefilter usable on this grid (cell origins exact to fp32 resolution)
-  int use_tile = 1;               // fp32 prefilter search (k_icp_search_f32) when tile_ok; 0: per-lane fp64 search
+  int use_tile = 1;               // cooperative fp32 prefilter search (k_icp_search_coop) when tile_ok; 0: per-lane fp64 search
   int tile_stats = 0;             // collect g_tile_stats
-  int force_generic = 0;          // tests: run the generic per-lane fp64 pass instead of the wave-tile pass
   uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
   size_t cap_tgt = 0, cap_nrm = 0, cap_cells = 0;
 
