@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -136,10 +137,12 @@ const char *o3d_last_error(const o3d_ctx *ctx) { return ctx ? ctx->err.c_str() :
 }  // extern "C"
 
 struct o3d_ctx_full : o3d_ctx {
+  std::recursive_mutex mu;  // one call in flight per context: concurrent callers of the same context are serialised
   o3d_staging stage;
   std::vector<o3d_ctx *> workers;  // contexts of the batch worker threads (created on first use, kept)
 };
 static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
+#define O3D_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock__(static_cast<o3d_ctx_full *>(ctx)->mu)
 
 extern "C" {
 
@@ -195,6 +198,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
 
 int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream, which is what torch's default stream is
@@ -203,6 +207,7 @@ int o3d_ctx_set_stream(o3d_ctx *ctx, void *hip_stream) {
 
 int o3d_ctx_use_own_stream(o3d_ctx *ctx) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = ctx->own_stream;
@@ -213,6 +218,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
                   double max_dist, const double init[16], int estimation, int with_scaling, double rel_fitness, double rel_rmse,
                   int max_iter, int mem, int64_t n_src_global) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   ctx->icp_ready = 0;
   if (!(max_dist > 0.0)) return o3d_fail(ctx, O3D_ERR_INVALID_DISTANCE, "%s", o3d_status_string(O3D_ERR_INVALID_DISTANCE));
   if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
@@ -296,6 +302,7 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
 
 int o3d_icp_pass(o3d_ctx *ctx) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
@@ -305,6 +312,7 @@ int o3d_icp_pass(o3d_ctx *ctx) {
 
 int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out) {
   if (!ctx || !dev_sums_out) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_pass_to before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
@@ -313,6 +321,7 @@ int o3d_icp_pass_to(o3d_ctx *ctx, double *dev_sums_out) {
 
 int o3d_icp_step(o3d_ctx *ctx) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_step before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   ctx->enq_passes++;
@@ -322,6 +331,7 @@ int o3d_icp_step(o3d_ctx *ctx) {
 
 int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   ctx->use_tile = force_generic_pass ? 0 : 1;
   ctx->tile_stats = collect_tile_stats;
   return O3D_OK;
@@ -329,6 +339,7 @@ int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) 
 
 int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
   if (!ctx || !host_out) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "no source loaded");
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipMemcpyAsync(host_out, ctx->src_perm, sizeof(uint32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
@@ -338,6 +349,7 @@ int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
 
 int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
   if (!ctx || !out) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   unsigned long long t[8];
   O3D_TRY(o3d_read_tile_stats(ctx, t, reset));
@@ -347,6 +359,7 @@ int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
 
 int o3d_icp_profile(o3d_ctx *ctx, int enable) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   ctx->prof_on = enable ? 1 : 0;
   ctx->prof_n = 0;
   return O3D_OK;
@@ -362,6 +375,7 @@ int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count) {
 
 int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double tot[2] = {0, 0};
@@ -385,6 +399,7 @@ double *o3d_icp_local_sums(o3d_ctx *ctx) { return ctx ? ctx->sums : nullptr; }
 
 int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks) {
   if (!ctx || !dev_all_sums || n_ranks < 1) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_solve before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   return o3d_launch_solve(ctx, dev_all_sums, n_ranks);
@@ -392,6 +407,7 @@ int o3d_icp_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks) {
 
 int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_poll before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
@@ -405,6 +421,7 @@ int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes) {
 int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
                    double *out_rmse, int *out_iters) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_finish before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   if (out_corr && ctx->n_src > 0) {
@@ -428,6 +445,7 @@ int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, i
 
 int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows) {
   if (!ctx || !host_log) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_get_log before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   int done = 0, passes = 0;
@@ -444,6 +462,7 @@ int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows)
 
 int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
   if (!ctx || !out_ms) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   out_ms[0] = ctx->setup_ms[0];
   out_ms[1] = ctx->setup_ms[1];
   return O3D_OK;
@@ -453,6 +472,8 @@ int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, con
                          int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
                          double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
                          int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);  // held for the whole call
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
                         rel_rmse, max_iter, mem, n_src));
   // Registration.cpp:154-166.  The whole loop is enqueued without host round trips; kernels past the break are
@@ -479,6 +500,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
                                double *out_fitness, double *out_rmse, int *out_iters, int *out_status) {
   if (!c) return O3D_ERR_INVALID_ARG;
   o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
+  O3D_LOCK(c);
   if (n_pairs < 0 || (n_pairs > 0 && (!src_xyz || !n_src || !tgt_xyz || !n_tgt)))
     return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
   if (n_pairs == 0) return O3D_OK;
@@ -533,6 +555,7 @@ int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src
                               double max_dist, const double T[16], int mem, int32_t *out_corr, int64_t *out_n_corr,
                               double *out_fitness, double *out_rmse) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!(max_dist > 0.0)) {  // Registration.cpp:45-47: an empty result, not an error
     DeviceGuard guard(ctx->device);
     if (out_corr && n_src > 0) {
@@ -558,6 +581,7 @@ int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src
 
 int o3d_icp_set_update(o3d_ctx *ctx, const double update_colmajor[16]) {
   if (!ctx || !update_colmajor) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_set_update before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   return o3d_launch_set_update(ctx, update_colmajor);
@@ -565,6 +589,7 @@ int o3d_icp_set_update(o3d_ctx *ctx, const double update_colmajor[16]) {
 
 int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_rmse) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (!ctx->icp_ready || !ctx->sums_valid)
     return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_fetch must directly follow o3d_icp_pass (or o3d_icp_step) on this context");
   DeviceGuard guard(ctx->device);
@@ -591,6 +616,7 @@ int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr,
 static int pairs_common(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
                         const int32_t *pairs, int64_t n_pairs, int estimation, int with_scaling, int mem, double host_out[19]) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
     return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path", estimation);
   if (n_src < 0 || n_tgt < 0 || n_pairs < 0 || (n_pairs > 0 && (!pairs || !src_xyz || !tgt_xyz)))
@@ -645,6 +671,7 @@ int o3d_compute_rmse(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const d
 int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
                            double max_dist, const double T[16], int mem, double out_gtg[36]) {
   if (!ctx || !out_gtg) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   for (int i = 0; i < 36; i++) out_gtg[i] = 0.0;
   if (!(max_dist > 0.0)) return O3D_OK;  // Registration.cpp:45-47: no correspondences, GTG stays zero
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem, n_src));
@@ -670,6 +697,7 @@ int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, c
 int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel_size,
                           int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_voxel_index, int64_t *out_m) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_voxel_down_sample_impl(ctx, xyz, nrm, col, n, voxel_size, mem, out_xyz, out_nrm, out_col, out_voxel_index, out_m);
 }
@@ -677,6 +705,7 @@ int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, co
 int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                          double *normals, int has_normals) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
 }

@@ -243,6 +243,35 @@ def RegistrationICPBatch(sources, targets, max_correspondence_distance, inits=No
     return out
 
 
+def MultiScaleICP(source, target, voxel_sizes, max_correspondence_distances=None, init=None, estimation=None,
+                  criteria=None, normal_radius_factor=2.0, normal_max_nn=30, ctx=None):
+    """Coarse-to-fine registration (BASELINE configs 3 and 4).  Build-defined: the reference has no multi-scale API; this
+    is the loop a caller writes over its three calls -- per scale v: VoxelDownSample(v) on both clouds
+    (PointCloud.cpp:273-306), EstimateNormals(Hybrid(normal_radius_factor * v, normal_max_nn)) on the target for
+    point-to-plane (EstimateNormals.cpp:320-351), RegistrationICP with max distance 2 v (or the given one) starting from the
+    previous scale's transformation (Registration.cpp:129-168).  voxel_size <= 0 uses the clouds as they are.
+    Returns (final RegistrationResult, [per-scale RegistrationResult])."""
+    from ..geometry import KDTreeSearchParamHybrid
+    ctx = ctx or _lib.default_context()
+    estimation = estimation or TransformationEstimationPointToPlane()
+    T = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+    p2l = estimation.GetTransformationEstimationType() == _lib.EST_POINT_TO_PLANE
+    results = []
+    for k, v in enumerate(voxel_sizes):
+        src_v = source.VoxelDownSample(v, ctx=ctx) if v > 0 else source
+        tgt_v = target.VoxelDownSample(v, ctx=ctx) if v > 0 else target
+        if p2l and not (v <= 0 and tgt_v.HasNormals()):
+            tgt_v = PointCloud(tgt_v.points_)
+            tgt_v.EstimateNormals(KDTreeSearchParamHybrid(normal_radius_factor * v, normal_max_nn), ctx=ctx)
+        r = max_correspondence_distances[k] if max_correspondence_distances is not None else 2.0 * v
+        crit = criteria[k] if isinstance(criteria, (list, tuple)) else criteria
+        res = RegistrationICP(src_v, tgt_v, r, T, estimation, crit, ctx=ctx)
+        res.n_source_, res.n_target_ = len(src_v.points_), len(tgt_v.points_)
+        results.append(res)
+        T = res.transformation_
+    return results[-1], results
+
+
 def GetInformationMatrixFromPointClouds(source, target, max_correspondence_distance, transformation, ctx=None):
     """GetInformationMatrixFromPointClouds, Registration.cpp:303-355.  Returns the 6x6 GTG."""
     ctx = ctx or _lib.default_context()

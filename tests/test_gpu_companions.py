@@ -161,3 +161,32 @@ def test_batch_reports_per_pair_errors(ctx):
         reg.RegistrationICPBatch([src, src], [tgt, tgt], -1.0, ctx=ctx)
     assert ei.value.status == 1  # Registration.cpp:134-136
     assert reg.RegistrationICPBatch([], [], 1.0, ctx=ctx) == []
+
+
+def test_multi_scale_pipeline_matches_oracle_chain(ctx, oracle):
+    """BASELINE configs 3 / 4 in miniature: VoxelDownSample -> EstimateNormals(hybrid) -> point-to-plane ICP per scale,
+    coarse to fine, each scale starting from the previous transformation; the oracle runs the same chain."""
+    geometry, reg = _reg()
+    sc = make_scene(60000, 60000, cfg_id=23, theta_deg=1.0, tau=(2.0, -1.5, 1.0))
+    s = sc["spacing"]
+    scales = [4 * s, 2 * s]
+    crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 20)
+    final, per_scale = reg.MultiScaleICP(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"]), scales,
+                                         criteria=crit, ctx=ctx)
+    T = np.eye(4)
+    for k, v in enumerate(scales):
+        src_v = oracle.voxel_down_sample(sc["source"], v)[0]
+        tgt_v = oracle.voxel_down_sample(sc["target"], v)[0]
+        nrm_v = oracle.estimate_normals(tgt_v, oracle.HYBRID, 30, 2 * v)
+        ref = oracle.registration_icp(src_v, tgt_v, 2 * v, T, 2, nrm_v, max_iter=20)
+        got = per_scale[k]
+        assert got.n_source_ == len(src_v) and got.n_target_ == len(tgt_v)
+        assert got.iterations_ == ref.iterations
+        assert np.array_equal(got.corr_, ref.corr)
+        assert rel_err(got.transformation_, ref.transformation) < TOL
+        assert rel_err(got.fitness_, ref.fitness) < TOL and rel_err(got.inlier_rmse_, ref.inlier_rmse) < TOL
+        T = ref.transformation
+    assert final is per_scale[-1]
+    # the chain recovers the known motion to well below a spacing
+    err = np.abs(final.transformation_ - sc["T_true"]).max()
+    assert err < 0.2 * s
