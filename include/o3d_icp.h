@@ -58,7 +58,7 @@ typedef enum {
 typedef enum { O3D_MEM_HOST = 0, O3D_MEM_DEVICE = 1 } o3d_mem;
 
 /* TransformationEstimationType, pipelines/registration/TransformationEstimation.h:45-50 */
-typedef enum { O3D_EST_POINT_TO_POINT = 1, O3D_EST_POINT_TO_PLANE = 2 } o3d_estimation;
+typedef enum { O3D_EST_POINT_TO_POINT = 1, O3D_EST_POINT_TO_PLANE = 2, O3D_EST_COLORED_ICP = 3 } o3d_estimation;
 
 /* KDTreeSearchParam::SearchType, geometry/KDTreeSearchParam.h:35-107 */
 typedef enum { O3D_SEARCH_KNN = 0, O3D_SEARCH_RADIUS = 1, O3D_SEARCH_HYBRID = 2 } o3d_search;
@@ -96,6 +96,19 @@ O3D_API int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_
 O3D_API int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
                               double max_correspondence_distance, const double transformation_colmajor[16], int mem,
                               int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
+
+/* RegistrationColoredICP, pipelines/registration/ColoredICP.cpp:205-211: InitializePointCloudForColoredICP (:68-123, the
+ * per-target-point colour gradient over KDTreeSearchParamHybrid(2 * max_distance, 30)) followed by RegistrationICP with
+ * TransformationEstimationForColoredICP::ComputeTransformation (:125-177: a geometric and a photometric row per
+ * correspondence through the multi-row utility::ComputeJTJandJTr, utility/Eigen.cpp:203-249).  Colours are 3 doubles per
+ * point (PointCloud::colors_).  lambda_geometric outside [0, 1] becomes 0.968 (:50-53).  Without source or target
+ * colours every update is the identity (:127-128), as in the reference.  out_corr / out_gradients (n_tgt x 3) may be NULL. */
+O3D_API int o3d_registration_colored_icp(o3d_ctx *ctx, const double *src_xyz, const double *src_col, int64_t n_src,
+                                 const double *tgt_xyz, const double *tgt_nrm, const double *tgt_col, int64_t n_tgt,
+                                 double max_distance, const double init_colmajor[16], double lambda_geometric,
+                                 double relative_fitness, double relative_rmse, int max_iteration, int mem,
+                                 double out_transformation[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
+                                 double *out_inlier_rmse, int *out_iterations, double *out_gradients);
 
 /* RegistrationICP over a batch of independent pairs (BASELINE config 5: thousands of small fragment pairs; the reference
  * would call Registration.cpp:129-168 in a loop).  Pair p uses src_xyz[p] (n_src[p] points), tgt_xyz[p], tgt_nrm[p]

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libo3d_amd.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-EST_POINT_TO_POINT, EST_POINT_TO_PLANE = 1, 2
+EST_POINT_TO_POINT, EST_POINT_TO_PLANE, EST_COLORED_ICP = 1, 2, 3
 SEARCH_KNN, SEARCH_RADIUS, SEARCH_HYBRID = 0, 1, 2
 LOG_STRIDE = 52
 STATUS_OK = 0
@@ -33,6 +33,9 @@ _SIGNATURES = {
                                        C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int)]),
     "o3d_evaluate_registration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp,
                                             C.c_int, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp]),
+    "o3d_registration_colored_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int64, C.c_double, c_dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                               c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int), C.c_void_p]),
     "o3d_registration_icp_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

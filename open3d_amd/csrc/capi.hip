@@ -22,6 +22,9 @@ int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
 int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
                      const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad);
 int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]);
+int o3d_launch_color_gather(o3d_ctx *ctx, const double *d_tgt_col, const double *d_grad, const double *d_src_col);
+int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double radius,
+                            int max_nn, double *d_grad);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
                                int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
 int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
@@ -101,8 +104,8 @@ int to_device(o3d_ctx *ctx, const void *p, size_t bytes, int mem, void **slot_pt
 }  // namespace
 
 struct o3d_staging {  // host->device staging of caller buffers (kept on the context, grow-only)
-  void *p[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t cap[4] = {0, 0, 0, 0};
+  void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // tgt, nrm, src, pairs, tgt colours, src colours, gradients
+  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 static o3d_staging *staging_of(o3d_ctx *ctx);
 
@@ -187,8 +190,10 @@ void o3d_ctx_destroy(o3d_ctx *c) {
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 7; i++)
     if (ctx->stage.p[i]) (void)hipFree(ctx->stage.p[i]);
+  if (ctx->tcol_sorted) (void)hipFree(ctx->tcol_sorted);
+  if (ctx->sint_sorted) (void)hipFree(ctx->sint_sorted);
   for (hipEvent_t e : ctx->prof_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -214,17 +219,21 @@ int o3d_ctx_use_own_stream(o3d_ctx *ctx) {
   return O3D_OK;
 }
 
-int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
-                  double max_dist, const double init[16], int estimation, int with_scaling, double rel_fitness, double rel_rmse,
-                  int max_iter, int mem, int64_t n_src_global) {
+// o3d_icp_setup, plus the coloured-ICP inputs (src_col / tgt_col / lambda_geometric; out_grad nullable, `mem` space).
+static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
+                          double max_dist, const double init[16], int estimation, int with_scaling, double rel_fitness,
+                          double rel_rmse, int max_iter, int mem, int64_t n_src_global, const double *src_col, const double *tgt_col,
+                          double lambda_geometric, double *out_grad) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);
   ctx->icp_ready = 0;
   if (!(max_dist > 0.0)) return o3d_fail(ctx, O3D_ERR_INVALID_DISTANCE, "%s", o3d_status_string(O3D_ERR_INVALID_DISTANCE));
-  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE && estimation != O3D_EST_COLORED_ICP)
     return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path", estimation);
-  if (estimation == O3D_EST_POINT_TO_PLANE && (!tgt_nrm || n_tgt <= 0))
+  if (estimation != O3D_EST_POINT_TO_POINT && (!tgt_nrm || n_tgt <= 0))
     return o3d_fail(ctx, O3D_ERR_NEED_NORMALS, "%s", o3d_status_string(O3D_ERR_NEED_NORMALS));
+  if (estimation == O3D_EST_COLORED_ICP && (!src_col || !tgt_col))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "coloured ICP set up without colours");
   if (n_src < 0 || n_tgt < 0 || !init || (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz) || max_iter < 0)
     return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
   if (n_src >= ((int64_t)1 << 31) || n_tgt >= ((int64_t)1 << 31))
@@ -239,19 +248,40 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
 
   const void *d_tgt, *d_nrm, *d_src;
   O3D_TRY(to_device(ctx, tgt_xyz, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[0], &sg->cap[0], &d_tgt));
-  O3D_TRY(to_device(ctx, estimation == O3D_EST_POINT_TO_PLANE ? tgt_nrm : nullptr, sizeof(double) * 3 * (size_t)n_tgt, mem,
+  O3D_TRY(to_device(ctx, estimation != O3D_EST_POINT_TO_POINT ? tgt_nrm : nullptr, sizeof(double) * 3 * (size_t)n_tgt, mem,
                     &sg->p[1], &sg->cap[1], &d_nrm));
+  const void *d_tcol = nullptr, *d_scol = nullptr;
+  if (estimation == O3D_EST_COLORED_ICP) {
+    // InitializePointCloudForColoredICP (ColoredICP.cpp:68-123, :209): gradients over Hybrid(2 * max_distance, 30); this
+    // uses the context's grid, which is then rebuilt with the cell size of the correspondence search
+    O3D_TRY(to_device(ctx, tgt_col, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[4], &sg->cap[4], &d_tcol));
+    O3D_TRY(to_device(ctx, src_col, sizeof(double) * 3 * (size_t)n_src, mem, &sg->p[5], &sg->cap[5], &d_scol));
+    O3D_TRY(o3d_reserve(ctx, &sg->p[6], &sg->cap[6], sizeof(double) * 3 * (size_t)(n_tgt > 0 ? n_tgt : 1)));
+    O3D_TRY(o3d_color_gradient_impl(ctx, (const double *)d_tgt, (const double *)d_nrm, (const double *)d_tcol, n_tgt, max_dist * 2.0, 30,
+                                    (double *)sg->p[6]));
+    if (out_grad && n_tgt > 0)
+      O3D_HIP(ctx, hipMemcpyAsync(out_grad, sg->p[6], sizeof(double) * 3 * (size_t)n_tgt,
+                                  mem == O3D_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (lambda_geometric < 0.0 || lambda_geometric > 1.0) lambda_geometric = 0.968;  // ColoredICP.cpp:50-53
+    ctx->slg = sqrt(lambda_geometric);
+    ctx->slp = sqrt(1.0 - lambda_geometric);
+  }
   O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist));
   O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
   const int apply_init = is_identity(init) ? 0 : 1;  // Registration.cpp:150-152
   O3D_TRY(to_device(ctx, src_xyz, sizeof(double) * 3 * (size_t)n_src, mem, &sg->p[2], &sg->cap[2], &d_src));
   O3D_TRY(o3d_sort_source(ctx, (const double *)d_src, n_src, init, apply_init));
+  if (estimation == O3D_EST_COLORED_ICP) {
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tcol_sorted, &ctx->cap_tcol, sizeof(double4) * (size_t)(n_tgt > 0 ? n_tgt : 1)));
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->sint_sorted, &ctx->cap_sint, sizeof(double) * (size_t)(n_src > 0 ? n_src : 1)));
+    O3D_TRY(o3d_launch_color_gather(ctx, (const double *)d_tcol, (const double *)sg->p[6], (const double *)d_scol));
+  }
   O3D_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
 
   // loop state
   ctx->estimation = estimation;
-  ctx->has_tgt_normals = (estimation == O3D_EST_POINT_TO_PLANE) ? 1 : 0;
+  ctx->has_tgt_normals = (estimation != O3D_EST_POINT_TO_POINT) ? 1 : 0;
   ctx->thr = (double)(float)(max_dist * max_dist);  // geometry/KDTreeFlann.cpp:148
   ctx->max_iter = max_iter;
   int64_t g = (n_src + O3D_BLOCK - 1) / O3D_BLOCK;
@@ -298,6 +328,16 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   ctx->sums_valid = 0;
   ctx->icp_ready = 1;
   return O3D_OK;
+}
+
+int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm, int64_t n_tgt,
+                  double max_dist, const double init[16], int estimation, int with_scaling, double rel_fitness, double rel_rmse,
+                  int max_iter, int mem, int64_t n_src_global) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path of o3d_icp_setup", estimation);
+  return icp_setup_impl(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness, rel_rmse,
+                        max_iter, mem, n_src_global, nullptr, nullptr, 0.0, nullptr);
 }
 
 int o3d_icp_pass(o3d_ctx *ctx) {
@@ -468,16 +508,9 @@ int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
   return O3D_OK;
 }
 
-int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
-                         int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
-                         double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
-                         int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
-  if (!ctx) return O3D_ERR_INVALID_ARG;
-  O3D_LOCK(ctx);  // held for the whole call
-  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
-                        rel_rmse, max_iter, mem, n_src));
-  // Registration.cpp:154-166.  The whole loop is enqueued without host round trips; kernels past the break are
-  // no-ops (IcpState::done).  The host looks at the flag every kChunk iterations to stop enqueueing early.
+// Registration.cpp:154-166.  The whole loop is enqueued without host round trips; kernels past the break are no-ops
+// (IcpState::done).  The host looks at the flag every kChunk iterations to stop enqueueing early.
+static int run_icp_loop(o3d_ctx *ctx, int max_iter) {
   const int kChunk = 6;
   O3D_TRY(o3d_icp_step(ctx));
   int it = 0;
@@ -490,6 +523,52 @@ int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, con
       if (done) break;
     }
   }
+  return O3D_OK;
+}
+
+int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                         int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
+                         double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
+                         int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);  // held for the whole call
+  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
+                        rel_rmse, max_iter, mem, n_src));
+  O3D_TRY(run_icp_loop(ctx, max_iter));
+  return o3d_icp_finish(ctx, mem, out_T, out_corr, out_n_corr, out_fitness, out_rmse, out_iters);
+}
+
+int o3d_registration_colored_icp(o3d_ctx *ctx, const double *src_xyz, const double *src_col, int64_t n_src, const double *tgt_xyz,
+                                 const double *tgt_nrm, const double *tgt_col, int64_t n_tgt, double max_dist, const double init[16],
+                                 double lambda_geometric, double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16],
+                                 int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters,
+                                 double *out_gradients) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);  // held for the whole call
+  if (!src_col || !tgt_col) {
+    // ColoredICP.cpp:127-128: without colours every update is the identity; the loop of Registration.cpp:154-166 then
+    // stops after its first iteration with the result of the initial search (and zero gradients where they exist)
+    if (!(max_dist > 0.0)) return o3d_fail(ctx, O3D_ERR_INVALID_DISTANCE, "%s", o3d_status_string(O3D_ERR_INVALID_DISTANCE));
+    if (!tgt_nrm) return o3d_fail(ctx, O3D_ERR_NEED_NORMALS, "%s", o3d_status_string(O3D_ERR_NEED_NORMALS));
+    if (!init) return O3D_ERR_INVALID_ARG;
+    if (out_gradients && n_tgt > 0) {
+      DeviceGuard guard(ctx->device);
+      if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_gradients, 0, sizeof(double) * 3 * (size_t)n_tgt, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        memset(out_gradients, 0, sizeof(double) * 3 * (size_t)n_tgt);
+      }
+    }
+    O3D_TRY(o3d_evaluate_registration(ctx, src_xyz, n_src, tgt_xyz, n_tgt, max_dist, init, mem, out_corr, out_n_corr, out_fitness,
+                                      out_rmse));
+    if (out_T) memcpy(out_T, init, sizeof(double) * 16);
+    if (out_iters) *out_iters = max_iter > 0 ? 1 : 0;
+    return O3D_OK;
+  }
+  O3D_TRY(icp_setup_impl(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, O3D_EST_COLORED_ICP, 0, rel_fitness, rel_rmse,
+                         max_iter, mem, n_src, src_col, tgt_col, lambda_geometric, out_gradients));
+  O3D_TRY(run_icp_loop(ctx, max_iter));
   return o3d_icp_finish(ctx, mem, out_T, out_corr, out_n_corr, out_fitness, out_rmse, out_iters);
 }
 

@@ -154,7 +154,7 @@ template <int EST>
 __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y, double z, const Best &b,
                                            const double4 &p, double n0, double n1, double n2, double cx0, double cy0,
                                            double cz0) {
-  if (EST == O3D_EST_POINT_TO_PLANE) {
+  if (EST != O3D_EST_POINT_TO_POINT) {
     double r = (x - p.x) * n0;
     r = r + (y - p.y) * n1;
     r = r + (z - p.z) * n2;
@@ -180,6 +180,63 @@ __device__ __forceinline__ void accumulate(double (&acc)[30], double x, double y
     acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
     acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
     acc[15] += (sx * sx + sy * sy) + sz * sz;
+  }
+  acc[O3D_SUM_D2] += b.d2;
+  acc[O3D_SUM_NC] += 1.0;
+}
+
+// The two rows of one correspondence of TransformationEstimationForColoredICP::ComputeTransformation
+// (ColoredICP.cpp:136-165): Jg / rg geometric (point-to-plane scaled by sqrt(lambda)), Jp / rp photometric.
+// tc = {target intensity, colour gradient}, is = source intensity.
+__device__ __forceinline__ void colored_rows(double x, double y, double z, const double4 &p, double n0, double n1, double n2,
+                                             const double4 &tc, double is, double slg, double slp, double (&Jg)[6], double &rg,
+                                             double (&Jp)[6], double &rp) {
+  double dot = (x - p.x) * n0;
+  dot = dot + (y - p.y) * n1;
+  dot = dot + (z - p.z) * n2;
+  Jg[0] = slg * (y * n2 - z * n1);
+  Jg[1] = slg * (z * n0 - x * n2);
+  Jg[2] = slg * (x * n1 - y * n0);
+  Jg[3] = slg * n0; Jg[4] = slg * n1; Jg[5] = slg * n2;
+  rg = slg * dot;
+  const double vpx = x - dot * n0, vpy = y - dot * n1, vpz = z - dot * n2;  // vs projected into vt's tangent plane
+  double is0 = tc.y * (vpx - p.x);
+  is0 = is0 + tc.z * (vpy - p.y);
+  is0 = is0 + tc.w * (vpz - p.z);
+  is0 = is0 + tc.x;
+  // -dit^T (I - n n^T)
+  const double nn[3] = {n0, n1, n2};
+  double m[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double a = (-tc.y) * ((c == 0 ? 1.0 : 0.0) - n0 * nn[c]);
+    a = a + (-tc.z) * ((c == 1 ? 1.0 : 0.0) - n1 * nn[c]);
+    a = a + (-tc.w) * ((c == 2 ? 1.0 : 0.0) - n2 * nn[c]);
+    m[c] = a;
+  }
+  Jp[0] = slp * (y * m[2] - z * m[1]);
+  Jp[1] = slp * (z * m[0] - x * m[2]);
+  Jp[2] = slp * (x * m[1] - y * m[0]);
+  Jp[3] = slp * m[0]; Jp[4] = slp * m[1]; Jp[5] = slp * m[2];
+  rp = slp * (is - is0);
+}
+
+// per-lane form of the coloured sums (k_icp_fixup): same layout as point-to-plane
+__device__ __forceinline__ void accumulate_colored(double (&acc)[30], double x, double y, double z, const Best &b, const double4 &p,
+                                                   double n0, double n1, double n2, const double4 &tc, double is, double slg,
+                                                   double slp) {
+  double J[2][6], r[2];
+  colored_rows(x, y, z, p, n0, n1, n2, tc, is, slg, slp, J[0], r[0], J[1], r[1]);
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = a; c < 6; c++) acc[k++] += J[j][a] * J[j][c];
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += J[j][a] * r[j];
+    acc[27] += r[j] * r[j];
   }
   acc[O3D_SUM_D2] += b.d2;
   acc[O3D_SUM_NC] += 1.0;
@@ -220,6 +277,10 @@ struct PassArgs {
   unsigned long long *pend;  // one bit per processing position: left to k_icp_fixup (word w covers positions 64w..64w+63)
   double *partials;
   double thr;
+  // coloured ICP only (ColoredICP.cpp:125-177)
+  const double4 *tcol;  // per sorted target point: {intensity, colour gradient}
+  const double *sint;   // per processing position: source intensity
+  double slg, slp;      // sqrt(lambda_geometric), sqrt(1 - lambda_geometric)
 };
 #define O3D_CORR_NONE (-1)
 #define O3D_CORR_PENDING (-2)
@@ -300,7 +361,7 @@ struct VBuf {
 template <int EST>
 __device__ __forceinline__ void make_v(double (&v)[kVComp], bool use, double x, double y, double z, const double4 &p, double n0,
                                        double n1, double n2, double d2, double cx0, double cy0, double cz0) {
-  if (EST == O3D_EST_POINT_TO_PLANE) {
+  if (EST != O3D_EST_POINT_TO_POINT) {
     double r = (x - p.x) * n0;
     r = r + (y - p.y) * n1;
     r = r + (z - p.z) * n2;
@@ -337,11 +398,35 @@ __device__ __forceinline__ void mfma_rank64(VBuf &vb, int lane, const double (&v
   wave_lds_sync();
 }
 
+// One correspondence's contribution to S: one vector for point-to-point / point-to-plane, two (geometric, photometric)
+// for coloured ICP.  Every lane of the wavefront must call it.
+template <int EST>
+__device__ __forceinline__ void push_sums(VBuf &vb, int lane, v4f64 &S, bool use, double x, double y, double z, const double4 &p,
+                                          double n0, double n1, double n2, double d2, double cx0, double cy0, double cz0,
+                                          const double4 &tc, double is, double slg, double slp) {
+  double v[kVComp];
+  if (EST == O3D_EST_COLORED_ICP) {
+    double Jg[6], Jp[6], rg, rp;
+    colored_rows(x, y, z, p, n0, n1, n2, tc, is, slg, slp, Jg, rg, Jp, rp);
+#pragma unroll
+    for (int c = 0; c < 6; c++) v[c] = use ? Jg[c] : 0.0;
+    v[6] = use ? rg : 0.0; v[7] = use ? d2 : 0.0; v[8] = use ? 1.0 : 0.0;
+    mfma_rank64(vb, lane, v, S);
+#pragma unroll
+    for (int c = 0; c < 6; c++) v[c] = use ? Jp[c] : 0.0;
+    v[6] = use ? rp : 0.0; v[7] = 0.0; v[8] = 0.0;
+    mfma_rank64(vb, lane, v, S);
+  } else {
+    make_v<EST>(v, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0);
+    mfma_rank64(vb, lane, v, S);
+  }
+}
+
 // Entry (row, col) of S that sum k of the partial row comes from (k < 30); point-to-point sum 15 is the trace term.
 template <int EST>
 __device__ __forceinline__ void sum_source(int k, int &row, int &col) {
   row = 15; col = 15;  // an entry that is always zero
-  if (EST == O3D_EST_POINT_TO_PLANE) {
+  if (EST != O3D_EST_POINT_TO_POINT) {
     if (k < 21) {
       int a = 0, rem = k;
       while (rem >= 6 - a) { rem -= 6 - a; a++; }
@@ -404,15 +489,16 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
     int32_t c = O3D_CORR_NONE;
     if (i < end) c = a.corr[i];
     bool use = c >= 0 || c == O3D_CORR_CANDIDATE;
-    double x = 0.0, y = 0.0, z = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, d2 = 0.0;
-    double4 p = make_double4(0.0, 0.0, 0.0, 0.0);
+    double x = 0.0, y = 0.0, z = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, d2 = 0.0, is = 0.0;
+    double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
     if (use) {
       const uint32_t pos = a.pos[i];
       x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
       p = a.tgt[pos];
-      if (EST == O3D_EST_POINT_TO_PLANE) {
+      if (EST != O3D_EST_POINT_TO_POINT) {
         n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
       }
+      if (EST == O3D_EST_COLORED_ICP) { tc = a.tcol[pos]; is = a.sint[i]; }
       const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
       d2 = ddx * ddx;
       d2 = d2 + ddy * ddy;
@@ -427,9 +513,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
         }
       }
     }
-    double v[kVComp];
-    make_v<EST>(v, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0);
-    mfma_rank64(vb, lane, v, S);
+    push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
   }
   __syncthreads();  // every wavefront is done with its staging buffer
   mfma_reduce_store<EST>(S, red, a.partials, chunk);
@@ -602,8 +686,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   // latency is not exposed.
   bool use_p = false;  // carried from the previous trip
   int64_t i_p = 0;
-  double4 p_p = make_double4(0.0, 0.0, 0.0, 0.0);
-  double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0;
+  double4 p_p = make_double4(0.0, 0.0, 0.0, 0.0), tc_p = make_double4(0.0, 0.0, 0.0, 0.0);
+  double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0, is_p = 0.0;
   auto consume = [&]() {
     double d2 = 0.0;
     if (use_p) {
@@ -619,9 +703,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
         use_p = false;
       }
     }
-    double v[kVComp];
-    make_v<EST>(v, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0);
-    mfma_rank64(wl.vb, lane, v, S);  // begins and ends with a wavefront LDS sync
+    // begins and ends with a wavefront LDS sync
+    push_sums<EST>(wl.vb, lane, S, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0, tc_p, is_p, a.slg, a.slp);
   };
 
   for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
@@ -721,9 +804,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     xs = x; ys = y; zs = z;
     if (use_p) {
       p_p = a.tgt[bpos];
-      if (EST == O3D_EST_POINT_TO_PLANE) {
+      if (EST != O3D_EST_POINT_TO_POINT) {
         n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
       }
+      if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[bpos]; is_p = a.sint[i]; }
     }
     if (a.stats) {
       const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
@@ -811,10 +895,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams 
         a.pos[i] = b.pos;
         if (b.idx >= 0) {
           double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-          if (EST == O3D_EST_POINT_TO_PLANE) {
+          if (EST != O3D_EST_POINT_TO_POINT) {
             n0 = a.nrm[3 * (size_t)b.pos]; n1 = a.nrm[3 * (size_t)b.pos + 1]; n2 = a.nrm[3 * (size_t)b.pos + 2];
           }
-          accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, cx0, cy0, cz0);
+          if (EST == O3D_EST_COLORED_ICP)
+            accumulate_colored(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, a.tcol[b.pos], a.sint[i], a.slg, a.slp);
+          else
+            accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, cx0, cy0, cz0);
         }
       }
       fill = 0;
@@ -1082,7 +1169,7 @@ __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_n
   double upd[16];
   mat4_identity(upd);
   if (nc > 0.0) {
-    if (st->estimation == O3D_EST_POINT_TO_PLANE) {
+    if (st->estimation != O3D_EST_POINT_TO_POINT) {  // point-to-plane and coloured ICP: 6x6 normal equations
       if (has_normals) {
         double A[36], b[6], x[6];
         int k = 0;
@@ -1256,6 +1343,23 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, 
   out[18] = nc;
 }
 
+__global__ __launch_bounds__(O3D_BLOCK) void k_gather_tcol(const double4 *__restrict__ tgt_sorted, const double *__restrict__ col,
+                                                            const double *__restrict__ grad, int64_t n, double4 *__restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const size_t i = (size_t)__double_as_longlong(tgt_sorted[p].w);
+    const double it = (col[3 * i] + col[3 * i + 1] + col[3 * i + 2]) / 3.0;
+    out[p] = make_double4(it, grad[3 * i], grad[3 * i + 1], grad[3 * i + 2]);
+  }
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_gather_sint(const uint32_t *__restrict__ perm, const double *__restrict__ col, int64_t n,
+                                                            double *__restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const size_t i = perm[p];
+    out[p] = (col[3 * i] + col[3 * i + 1] + col[3 * i + 2]) / 3.0;
+  }
+}
+
 // Caller-computed update (estimations that stay on the host, e.g. ColoredICP or a user subclass): what
 // Registration.cpp:157-159 does with the result of the virtual ComputeTransformation.
 struct Mat16 {
@@ -1323,7 +1427,17 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
   pa.pend = ctx->pend_mask;
-  const bool p2l = ctx->estimation == O3D_EST_POINT_TO_PLANE;
+  pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
+  const int est = ctx->estimation;
+#define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \
+  do {                                                                                                                     \
+    if (est == O3D_EST_POINT_TO_PLANE)                                                                                     \
+      hipLaunchKernelGGL(KERNEL<O3D_EST_POINT_TO_PLANE>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);        \
+    else if (est == O3D_EST_COLORED_ICP)                                                                                   \
+      hipLaunchKernelGGL(KERNEL<O3D_EST_COLORED_ICP>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);           \
+    else                                                                                                                   \
+      hipLaunchKernelGGL(KERNEL<O3D_EST_POINT_TO_POINT>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);        \
+  } while (0)
   const int gf = O3D_FIX_GRID;
   // Default: the cooperative fp32-prefilter search with the estimate's sums fused in, then the exact fixup of what it
   // left undecided.  Alternative (grids too large for the fp32 error bound, or forced by o3d_debug_set): the per-lane
@@ -1332,16 +1446,13 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const int grows = fused ? ctx->search_grid : ctx->pass_grid;
   const int nparts = grows + gf;
   if (fused) {
-    if (p2l) hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_PLANE>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
-    else hipLaunchKernelGGL(k_icp_search_coop<O3D_EST_POINT_TO_POINT>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-    if (p2l) hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_PLANE>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
-    else hipLaunchKernelGGL(k_icp_fixup<O3D_EST_POINT_TO_POINT>, dim3(gf), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp, grows);
+    O3D_LAUNCH_EST(k_icp_fixup, gf, pa, ctx->gp, grows);
   } else {
     hipLaunchKernelGGL(k_icp_search, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-    if (p2l) hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_PLANE>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa);
-    else hipLaunchKernelGGL(k_icp_accumulate_mfma<O3D_EST_POINT_TO_POINT>, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa);
+    O3D_LAUNCH_EST(k_icp_accumulate_mfma, grows, pa);
     O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)grows * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {
@@ -1354,6 +1465,26 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   else
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, nparts, ctx->state,
                        dev_sums_out);
+#undef O3D_LAUNCH_EST
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+// Coloured ICP: per sorted target point {intensity, colour gradient}, per processing position the source intensity
+// ((r + g + b) / 3, ColoredICP.cpp:86,152-153).
+int o3d_launch_color_gather(o3d_ctx *ctx, const double *d_tgt_col, const double *d_grad, const double *d_src_col) {
+  if (ctx->n_tgt_grid > 0) {
+    int64_t g = (ctx->n_tgt_grid + O3D_BLOCK - 1) / O3D_BLOCK;
+    if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+    hipLaunchKernelGGL(k_gather_tcol, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->tgt_sorted, d_tgt_col, d_grad,
+                       ctx->n_tgt_grid, ctx->tcol_sorted);
+  }
+  if (ctx->n_src > 0) {
+    int64_t g = (ctx->n_src + O3D_BLOCK - 1) / O3D_BLOCK;
+    if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
+    hipLaunchKernelGGL(k_gather_sint, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->src_perm, d_src_col, ctx->n_src,
+                       ctx->sint_sorted);
+  }
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

@@ -80,6 +80,11 @@ struct o3d_ctx {
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
   unsigned long long *pend_mask = nullptr;  // one bit per processing position: left to k_icp_fixup
   size_t cap_src = 0;
+  // coloured ICP
+  double4 *tcol_sorted = nullptr;  // per sorted target point {intensity, colour gradient}
+  double *sint_sorted = nullptr;   // per processing position: source intensity
+  size_t cap_tcol = 0, cap_sint = 0;
+  double slg = 0.0, slp = 0.0;     // sqrt(lambda_geometric), sqrt(1 - lambda_geometric)
 
   // loop
   IcpState *state = nullptr;   // device

@@ -371,6 +371,130 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
   }
 }
 
+// 3 x 3 symmetric solve with Eigen's LDLT (pivot on the largest |diagonal|, zero pivots give a zero component):
+// SolveLinearSystemPSD without checks, utility/Eigen.cpp:85.
+__device__ void ldlt_solve3(const double *A, const double *b, double *x) {
+  double M[9];
+  int tr[3];
+  for (int i = 0; i < 9; i++) M[i] = A[i];
+#define MM(i, j) M[(i) * 3 + (j)]
+  for (int k = 0; k < 3; k++) {
+    int p = k;
+    double big = fabs(MM(k, k));
+    for (int i = k + 1; i < 3; i++)
+      if (fabs(MM(i, i)) > big) { big = fabs(MM(i, i)); p = i; }
+    tr[k] = p;
+    if (p != k) {
+      for (int j = 0; j < k; j++) { const double t = MM(k, j); MM(k, j) = MM(p, j); MM(p, j) = t; }
+      for (int i = p + 1; i < 3; i++) { const double t = MM(i, k); MM(i, k) = MM(i, p); MM(i, p) = t; }
+      for (int i = k + 1; i < p; i++) { const double t = MM(i, k); MM(i, k) = MM(p, i); MM(p, i) = t; }
+      { const double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t; }
+    }
+    if (k > 0) {
+      double temp[3];
+      for (int j = 0; j < k; j++) temp[j] = MM(j, j) * MM(k, j);
+      double s = 0;
+      for (int j = 0; j < k; j++) s += MM(k, j) * temp[j];
+      MM(k, k) -= s;
+      for (int i = k + 1; i < 3; i++) {
+        double a = 0;
+        for (int j = 0; j < k; j++) a += MM(i, j) * temp[j];
+        MM(i, k) -= a;
+      }
+    }
+    const double akk = MM(k, k);
+    if (fabs(akk) > 0)
+      for (int i = k + 1; i < 3; i++) MM(i, k) /= akk;
+  }
+  double y[3];
+  for (int i = 0; i < 3; i++) y[i] = b[i];
+  for (int k = 0; k < 3; k++)
+    if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < i; j++) y[i] -= MM(i, j) * y[j];
+  for (int i = 0; i < 3; i++) {
+    if (fabs(MM(i, i)) > 2.2250738585072014e-308) y[i] /= MM(i, i);
+    else y[i] = 0;
+  }
+  for (int i = 2; i >= 0; i--)
+    for (int j = i + 1; j < 3; j++) y[i] -= MM(j, i) * y[j];
+  for (int k = 2; k >= 0; k--)
+    if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < 3; i++) x[i] = y[i];
+#undef MM
+}
+
+// InitializePointCloudForColoredICP, ColoredICP.cpp:68-123: per point the hybrid neighbourhood (the max_nn nearest with
+// d2 < thr, ascending by (d2, index) -- the query itself comes first), the least-squares colour gradient in the tangent
+// plane with the orthogonality row (:108-112), 3 x 3 normal equations solved by LDLT.  Fewer than 4 neighbours: zero.
+// normals / colours / grad are in the caller's order (3 doubles per point).
+__global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__restrict__ pts, int64_t n_grid,
+                                                               const uint32_t *__restrict__ cell_start, GridParams gp, int knn, double thr,
+                                                               const double *__restrict__ normals, const double *__restrict__ colors,
+                                                               double *__restrict__ grad) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  KList l;
+  l.d2 = reinterpret_cast<double *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.idx = l.pos + kNrmBlock * (size_t)knn;
+  l.cap = knn;
+  l.thr = thr;
+  for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
+    const double4 q = pts[p];
+    const size_t qi = (size_t)__double_as_longlong(q.w);
+    const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    l.count = 0;
+    for (int dz = -1; dz <= 1; dz++) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= gp.nz) continue;
+      for (int dy = -1; dy <= 1; dy++) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= gp.ny) continue;
+        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+        const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
+        const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+        for (uint32_t j = s; j < e; j++) {
+          const double4 t = pts[j];
+          const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+          double d2 = ddx * ddx;
+          d2 = d2 + ddy * ddy;
+          d2 = d2 + ddz * ddz;
+          if (d2 <= klist_worst(l)) klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+        }
+      }
+    }
+    double g[3] = {0.0, 0.0, 0.0};
+    const int nn = l.count;
+    if (nn >= 4) {
+      const double n0 = normals[3 * qi], n1 = normals[3 * qi + 1], n2 = normals[3 * qi + 2];
+      const double it = (colors[3 * qi] + colors[3 * qi + 1] + colors[3 * qi + 2]) / 3.0;
+      double AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Atb[3] = {0, 0, 0};
+      for (int i = 1; i <= nn; i++) {
+        double a[3], b;
+        if (i < nn) {
+          const double4 t = pts[l.pos[i * kNrmBlock]];
+          const size_t ai = l.idx[i * kNrmBlock];
+          const double dot = ((t.x - q.x) * n0 + (t.y - q.y) * n1) + (t.z - q.z) * n2;
+          a[0] = (t.x - dot * n0) - q.x; a[1] = (t.y - dot * n1) - q.y; a[2] = (t.z - dot * n2) - q.z;
+          b = (colors[3 * ai] + colors[3 * ai + 1] + colors[3 * ai + 2]) / 3.0 - it;
+        } else {
+          a[0] = (double)(nn - 1) * n0; a[1] = (double)(nn - 1) * n1; a[2] = (double)(nn - 1) * n2;
+          b = 0.0;
+        }
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 3; c++) AtA[r * 3 + c] += a[r] * a[c];
+          Atb[r] += a[r] * b;
+        }
+      }
+      ldlt_solve3(AtA, Atb, g);
+    }
+    grad[3 * qi] = g[0]; grad[3 * qi + 1] = g[1]; grad[3 * qi + 2] = g[2];
+  }
+}
+
 // Non-finite points are not in the grid: FLANN finds no finite-distance neighbour for them -> fewer than 3 -> (0,0,1).
 __global__ __launch_bounds__(O3D_BLOCK) void k_normals_nonfinite(const double *__restrict__ xyz, int64_t n, double *__restrict__ normals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -598,4 +722,26 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
   const int st = run();
   cleanup();
   return st;
+}
+
+// Colour gradients of a cloud on the device (all pointers device memory; d_grad: n x 3, zero for points outside the grid).
+// Rebuilds the context's grid over the cloud with cell size = radius.
+int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double radius,
+                            int max_nn, double *d_grad) {
+  if (n <= 0) return O3D_OK;
+  if (max_nn > kMaxKnn) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "colour gradient: max_nn > %d is not on the device path", kMaxKnn);
+  ctx->icp_ready = 0;
+  O3D_HIP(ctx, hipMemsetAsync(d_grad, 0, sizeof(double) * 3 * (size_t)n, ctx->stream));
+  if (!(radius > 0.0) || max_nn < 4) return O3D_OK;  // no point can collect 4 neighbours
+  O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius));
+  const int64_t ng = ctx->n_tgt_grid;
+  if (ng <= 0) return O3D_OK;
+  const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:148
+  const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)max_nn;
+  int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
+  g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+  hipLaunchKernelGGL(k_color_gradient, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp,
+                     max_nn, thr, d_nrm, d_col, d_grad);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
 }

@@ -243,6 +243,37 @@ def RegistrationICPBatch(sources, targets, max_correspondence_distance, inits=No
     return out
 
 
+def RegistrationColoredICP(source, target, max_distance, init=None, criteria=None, lambda_geometric=0.968, ctx=None,
+                           return_gradients=False):
+    """RegistrationColoredICP, ColoredICP.cpp:205-211 (colour gradients :68-123, estimation :125-177), on the device."""
+    ctx = ctx or _lib.default_context()
+    init = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+    criteria = criteria or ICPConvergenceCriteria()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    nrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    scol = np.ascontiguousarray(source.colors_, dtype=np.float64) if source.HasColors() else None
+    tcol = np.ascontiguousarray(target.colors_, dtype=np.float64) if target.HasColors() else None
+    T = np.zeros(16)
+    corr = np.empty(max(len(src), 1), np.int32)
+    grad = np.zeros((max(len(tgt), 1), 3)) if return_gradients else None
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    iters = C.c_int()
+    ctx.check(ctx._lib.o3d_registration_colored_icp(
+        ctx.handle, _lib.ptr(src), _lib.ptr(scol), len(src), _lib.ptr(tgt), _lib.ptr(nrm), _lib.ptr(tcol), len(tgt),
+        float(max_distance), _lib.colmajor(init).ctypes.data_as(_lib.c_dp), float(lambda_geometric), criteria.relative_fitness_,
+        criteria.relative_rmse_, criteria.max_iteration_, _lib.MEM_HOST, T.ctypes.data_as(_lib.c_dp), _lib.ptr(corr), C.byref(nc),
+        C.byref(fit), C.byref(rmse), C.byref(iters), _lib.ptr(grad)))
+    res = RegistrationResult(_lib.from_colmajor(T))
+    res.corr_ = corr[: len(src)].copy()
+    res.correspondence_set_ = _pairs(res.corr_)
+    res.fitness_, res.inlier_rmse_, res.iterations_ = fit.value, rmse.value, iters.value
+    if return_gradients:
+        res.color_gradient_ = grad[: len(tgt)]
+    return res
+
+
 def MultiScaleICP(source, target, voxel_sizes, max_correspondence_distances=None, init=None, estimation=None,
                   criteria=None, normal_radius_factor=2.0, normal_max_nn=30, ctx=None):
     """Coarse-to-fine registration (BASELINE configs 3 and 4).  Build-defined: the reference has no multi-scale API; this

@@ -215,6 +215,55 @@ def information_matrix(src, tgt, max_dist, T, brute=False):
     return G.reshape(6, 6)
 
 
+def color_gradient(pts, normals, colors, radius, max_nn=30):
+    """InitializePointCloudForColoredICP, ColoredICP.cpp:68-123 -> gradients [n,3]."""
+    pts, normals, colors = _pts(pts), _pts(normals), _pts(colors)
+    g = np.zeros_like(pts)
+    lib().orc_color_gradient(_d(pts), _d(normals), _d(colors), C.c_int64(len(pts)), C.c_double(radius), int(max_nn), _d(g))
+    return g
+
+
+def colored_compute(src, src_col, tgt, tgt_nrm, tgt_col, grad, corr, lambda_geometric=0.968):
+    """TransformationEstimationForColoredICP::ComputeTransformation, ColoredICP.cpp:125-177 -> (T, JTJ, JTr)."""
+    a = [_pts(x) for x in (src, src_col, tgt, tgt_nrm, tgt_col, grad)]
+    corr = np.ascontiguousarray(corr, np.int32)
+    T, JTJ, JTr = np.zeros(16), np.zeros(36), np.zeros(6)
+    lib().orc_colored_compute(*[_d(x) for x in a], _i(corr), C.c_int64(len(a[0])), C.c_double(lambda_geometric), _d(T), _d(JTJ), _d(JTr))
+    return _unmat(T), JTJ.reshape(6, 6), JTr
+
+
+def colored_rmse(src, src_col, tgt, tgt_nrm, tgt_col, grad, corr, lambda_geometric=0.968):
+    """ColoredICP.cpp:179-203 (sum of squared residuals)."""
+    a = [_pts(x) for x in (src, src_col, tgt, tgt_nrm, tgt_col, grad)]
+    corr = np.ascontiguousarray(corr, np.int32)
+    f = lib().orc_colored_rmse
+    f.restype = C.c_double
+    return f(*[_d(x) for x in a], _i(corr), C.c_int64(len(a[0])), C.c_double(lambda_geometric))
+
+
+def registration_colored_icp(src, src_col, tgt, tgt_nrm, tgt_col, max_dist, init=None, lambda_geometric=0.968, rel_fitness=1e-6,
+                             rel_rmse=1e-6, max_iter=30):
+    """RegistrationColoredICP, ColoredICP.cpp:205-211 -> ICPResult (+ .gradients)."""
+    src, src_col, tgt, tgt_nrm, tgt_col = [_pts(x) for x in (src, src_col, tgt, tgt_nrm, tgt_col)]
+    init = np.eye(4) if init is None else init
+    T = np.zeros(16)
+    corr = np.empty(max(len(src), 1), np.int32)
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    iters = C.c_int()
+    grad = np.zeros_like(tgt)
+    st = lib().orc_registration_colored_icp(_d(src), _d(src_col), C.c_int64(len(src)), _d(tgt), _d(tgt_nrm), _d(tgt_col),
+                                            C.c_int64(len(tgt)), C.c_double(max_dist), _d(_mat(init)), C.c_double(lambda_geometric),
+                                            C.c_double(rel_fitness), C.c_double(rel_rmse), int(max_iter), _d(T), _i(corr),
+                                            C.byref(nc), C.byref(fit), C.byref(rmse), C.byref(iters), _d(grad))
+    if st != 0:
+        raise ValueError("orc_registration_colored_icp status %d" % st)
+    r = ICPResult()
+    r.transformation, r.corr, r.n_corr = _unmat(T), corr[: len(src)], nc.value
+    r.fitness, r.inlier_rmse, r.iterations, r.gradients = fit.value, rmse.value, iters.value, grad
+    return r
+
+
 def voxel_down_sample(pts, voxel, normals=None, colors=None):
     """PointCloud.cpp:273-306 -> (points, normals|None, colors|None, voxel_index int32[M,3]); sorted by (z,y,x)."""
     pts = _pts(pts)

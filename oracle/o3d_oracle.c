@@ -842,6 +842,167 @@ ORC_EXPORT int orc_registration_icp(const double *src, int64_t ns, const double 
   return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Colored ICP, pipelines/registration/ColoredICP.cpp (row "next", rank 2).     */
+/* ------------------------------------------------------------------------- */
+static inline double intensity3(const double *c) { return (c[0] + c[1] + c[2]) / 3.0; }
+
+/* InitializePointCloudForColoredICP, ColoredICP.cpp:68-123: per target point the least-squares colour gradient in its
+ * tangent plane over the hybrid neighbourhood (radius, max_nn), zero when fewer than 4 neighbours.  grad: n x 3. */
+ORC_EXPORT void orc_color_gradient(const double *pts, const double *nrm, const double *col, int64_t n, double radius, int max_nn,
+                                   double *grad) {
+  orc_kdtree *kd = orc_kdtree_build(pts, n);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(max_nn > 0 ? max_nn : 1));
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)(max_nn > 0 ? max_nn : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t k = 0; k < n; k++) {
+      const double *vt = pts + 3 * k, *nt = nrm + 3 * k;
+      const double it = intensity3(col + 3 * k);
+      double *g = grad + 3 * k;
+      g[0] = g[1] = g[2] = 0.0;
+      const int nn = orc_kdtree_search_hybrid(kd, vt, radius, max_nn, idx, d2);
+      if (nn < 4) continue;
+      double AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Atb[3] = {0, 0, 0};
+      for (int i = 1; i <= nn; i++) { /* rows 0..nn-2 from neighbours 1..nn-1, row nn-1 the orthogonal constraint */
+        double a[3], b;
+        if (i < nn) {
+          const double *va = pts + 3 * (size_t)idx[i];
+          const double dot = ((va[0] - vt[0]) * nt[0] + (va[1] - vt[1]) * nt[1]) + (va[2] - vt[2]) * nt[2];
+          for (int d = 0; d < 3; d++) a[d] = (va[d] - dot * nt[d]) - vt[d];
+          b = intensity3(col + 3 * (size_t)idx[i]) - it;
+        } else {
+          for (int d = 0; d < 3; d++) a[d] = (double)(nn - 1) * nt[d];
+          b = 0.0;
+        }
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 3; c++) AtA[r * 3 + c] += a[r] * a[c];
+          Atb[r] += a[r] * b;
+        }
+      }
+      orc_ldlt_solve(3, AtA, Atb, g); /* SolveLinearSystemPSD without checks: always "success" (utility/Eigen.cpp:85) */
+    }
+    free(idx);
+    free(d2);
+  }
+  orc_kdtree_free(kd);
+}
+
+/* the two residuals and Jacobian rows of one correspondence, ColoredICP.cpp:136-165 */
+static void colored_rows(const double *vs, double is, const double *vt, const double *nt, double it, const double *dit, double slg,
+                         double slp, double *J0, double *r0, double *J1, double *r1) {
+  double c[3];
+  cross3(vs, nt, c);
+  for (int d = 0; d < 3; d++) { J0[d] = slg * c[d]; J0[3 + d] = slg * nt[d]; }
+  const double dot = ((vs[0] - vt[0]) * nt[0] + (vs[1] - vt[1]) * nt[1]) + (vs[2] - vt[2]) * nt[2];
+  *r0 = slg * dot;
+  double vp[3];
+  for (int d = 0; d < 3; d++) vp[d] = vs[d] - dot * nt[d];
+  const double is0 = ((dit[0] * (vp[0] - vt[0]) + dit[1] * (vp[1] - vt[1])) + dit[2] * (vp[2] - vt[2])) + it;
+  double M[9], ditM[3];
+  for (int r = 0; r < 3; r++)
+    for (int cc = 0; cc < 3; cc++) M[r * 3 + cc] = (r == cc ? 1.0 : 0.0) - nt[r] * nt[cc];
+  for (int cc = 0; cc < 3; cc++) ditM[cc] = ((-dit[0]) * M[0 * 3 + cc] + (-dit[1]) * M[1 * 3 + cc]) + (-dit[2]) * M[2 * 3 + cc];
+  cross3(vs, ditM, c);
+  for (int d = 0; d < 3; d++) { J1[d] = slp * c[d]; J1[3 + d] = slp * ditM[d]; }
+  *r1 = slp * (is - is0);
+}
+
+/* TransformationEstimationForColoredICP::ComputeTransformation, ColoredICP.cpp:125-177.  corr[i] = target index or -1. */
+ORC_EXPORT void orc_colored_compute(const double *src, const double *src_col, const double *tgt, const double *tgt_nrm,
+                                    const double *tgt_col, const double *grad, const int32_t *corr, int64_t ns, double lambda_geometric,
+                                    double *T, double *JTJ_out, double *JTr_out) {
+  int64_t nc = 0;
+  for (int64_t i = 0; i < ns; i++) nc += corr[i] >= 0;
+  mat4_identity(T);
+  if (nc == 0 || !tgt_nrm || !tgt_col || !src_col) return;
+  const double slg = sqrt(lambda_geometric), slp = sqrt(1.0 - lambda_geometric);
+  double JTJ[36], JTr[6], mb[6], x[6];
+  memset(JTJ, 0, sizeof JTJ);
+  memset(JTr, 0, sizeof JTr);
+  for (int64_t i = 0; i < ns; i++) {
+    const int32_t t = corr[i];
+    if (t < 0) continue;
+    double J[2][6], r[2];
+    colored_rows(src + 3 * i, intensity3(src_col + 3 * i), tgt + 3 * (size_t)t, tgt_nrm + 3 * (size_t)t, intensity3(tgt_col + 3 * (size_t)t),
+                 grad + 3 * (size_t)t, slg, slp, J[0], &r[0], J[1], &r[1]);
+    for (int j = 0; j < 2; j++)
+      for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) JTJ[a * 6 + b] += J[j][a] * J[j][b];
+        JTr[a] += J[j][a] * r[j];
+      }
+  }
+  for (int i = 0; i < 6; i++) mb[i] = -JTr[i];
+  orc_ldlt_solve(6, JTJ, mb, x);
+  orc_vec6_to_mat4(x, T);
+  if (JTJ_out) memcpy(JTJ_out, JTJ, sizeof JTJ);
+  if (JTr_out) memcpy(JTr_out, JTr, sizeof JTr);
+}
+
+/* TransformationEstimationForColoredICP::ComputeRMSE, ColoredICP.cpp:179-203: the SUM of the squared residuals (no mean, no root). */
+ORC_EXPORT double orc_colored_rmse(const double *src, const double *src_col, const double *tgt, const double *tgt_nrm,
+                                   const double *tgt_col, const double *grad, const int32_t *corr, int64_t ns, double lambda_geometric) {
+  const double slg = sqrt(lambda_geometric), slp = sqrt(1.0 - lambda_geometric);
+  double residual = 0.0;
+  for (int64_t i = 0; i < ns; i++) {
+    const int32_t t = corr[i];
+    if (t < 0) continue;
+    double J0[6], J1[6], r0, r1;
+    colored_rows(src + 3 * i, intensity3(src_col + 3 * i), tgt + 3 * (size_t)t, tgt_nrm + 3 * (size_t)t, intensity3(tgt_col + 3 * (size_t)t),
+                 grad + 3 * (size_t)t, slg, slp, J0, &r0, J1, &r1);
+    residual += r0 * r0 + r1 * r1;
+  }
+  return residual;
+}
+
+/* RegistrationColoredICP, ColoredICP.cpp:205-211: gradients over Hybrid(2 * max_distance, 30), then RegistrationICP
+ * (Registration.cpp:129-168) with the coloured estimation.  Returns 0 ok, 1 invalid distance, 2 target without normals. */
+ORC_EXPORT int orc_registration_colored_icp(const double *src, const double *src_col, int64_t ns, const double *tgt,
+                                            const double *tgt_nrm, const double *tgt_col, int64_t nt, double max_dist, const double *init,
+                                            double lambda_geometric, double rel_fitness, double rel_rmse, int max_iter, double *T_out,
+                                            int32_t *corr_out, int64_t *n_corr_out, double *fitness_out, double *rmse_out, int *iters_out,
+                                            double *grad_out /* nt x 3, nullable */) {
+  if (lambda_geometric < 0 || lambda_geometric > 1.0) lambda_geometric = 0.968; /* :50-53 */
+  double *grad = (double *)calloc((size_t)(nt > 0 ? nt : 1) * 3, sizeof(double));
+  if (tgt_nrm && tgt_col) orc_color_gradient(tgt, tgt_nrm, tgt_col, nt, max_dist * 2.0, 30, grad);
+  if (grad_out) memcpy(grad_out, grad, sizeof(double) * 3 * (size_t)nt);
+  if (max_dist <= 0.0) { free(grad); return 1; }
+  if (!tgt_nrm) { free(grad); return 2; }
+  double T[16];
+  memcpy(T, init, sizeof T);
+  orc_kdtree *kd = orc_kdtree_build(tgt, nt);
+  double *pcd = (double *)malloc(sizeof(double) * 3 * (size_t)(ns > 0 ? ns : 1));
+  memcpy(pcd, src, sizeof(double) * 3 * (size_t)ns);
+  if (!orc_is_identity(init)) orc_transform_points(init, pcd, ns);
+  int64_t nc;
+  double sd2, fit, rmse;
+  orc_correspondences(pcd, ns, tgt, nt, kd, max_dist, 0, corr_out, &nc, &sd2, &fit, &rmse);
+  int it = 0;
+  for (it = 0; it < max_iter; it++) {
+    double upd[16];
+    orc_colored_compute(pcd, src_col, tgt, tgt_nrm, tgt_col, grad, corr_out, ns, lambda_geometric, upd, NULL, NULL);
+    mat4_mul(upd, T, T);
+    orc_transform_points(upd, pcd, ns);
+    double bf = fit, br = rmse;
+    orc_correspondences(pcd, ns, tgt, nt, kd, max_dist, 0, corr_out, &nc, &sd2, &fit, &rmse);
+    if (fabs(bf - fit) < rel_fitness && fabs(br - rmse) < rel_rmse) { it++; break; }
+  }
+  memcpy(T_out, T, sizeof T);
+  *n_corr_out = nc;
+  *fitness_out = fit;
+  *rmse_out = rmse;
+  *iters_out = it;
+  free(pcd);
+  free(grad);
+  orc_kdtree_free(kd);
+  return 0;
+}
+
 /* EvaluateRegistration, Registration.cpp:118-127 */
 ORC_EXPORT int orc_evaluate_registration(const double *src, int64_t ns, const double *tgt, int64_t nt, double max_dist,
                                          const double *T, int use_brute, int32_t *corr_out, int64_t *n_corr, double *fitness,

@@ -190,3 +190,70 @@ def test_multi_scale_pipeline_matches_oracle_chain(ctx, oracle):
     # the chain recovers the known motion to well below a spacing
     err = np.abs(final.transformation_ - sc["T_true"]).max()
     assert err < 0.2 * s
+
+
+def _colored_scene(n_src, n_tgt, cfg_id):
+    """Height-field pair with a smooth colour texture sampled at the (untransformed) surface position."""
+    sc = make_scene(n_src, n_tgt, cfg_id=cfg_id, theta_deg=0.3, tau=(0.6, -0.4, 0.2))
+
+    def tex(p):
+        x, y = p[:, 0], p[:, 1]
+        r = 0.5 + 0.4 * np.sin(2.1 * x) * np.cos(1.7 * y)
+        g = 0.5 + 0.4 * np.cos(1.3 * x + 0.5)
+        b = 0.5 + 0.4 * np.sin(0.9 * y - 0.3) * np.sin(1.1 * x)
+        return np.stack([r, g, b], axis=1)
+
+    Tt = sc["T_true"]
+    src_world = sc["source"] @ Tt[:3, :3].T + Tt[:3, 3]   # where the source points really sit on the surface
+    sc["source_colors"], sc["target_colors"] = tex(src_world), tex(sc["target"])
+    return sc
+
+
+@pytest.mark.parametrize("n", [3000, 30000])
+def test_registration_colored_icp_matches_oracle(ctx, oracle, n):
+    geometry, reg = _reg()
+    sc = _colored_scene(n, n + 400, cfg_id=61 + n)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    source = geometry.PointCloud(sc["source"], colors=sc["source_colors"])
+    target = geometry.PointCloud(sc["target"], normals=nrm, colors=sc["target_colors"])
+    r = 2.5 * s
+    got = reg.RegistrationColoredICP(source, target, r, np.eye(4), reg.ICPConvergenceCriteria(1e-6, 1e-6, 20), ctx=ctx,
+                                     return_gradients=True)
+    ref = oracle.registration_colored_icp(sc["source"], sc["source_colors"], sc["target"], nrm, sc["target_colors"], r, max_iter=20)
+    # gradients: same neighbour sets, 3x3 normal equations summed in the same order -> tight
+    scale = np.abs(ref.gradients).max()
+    assert scale > 0
+    assert np.abs(got.color_gradient_ - ref.gradients).max() < 1e-9 * scale
+    assert got.iterations_ == ref.iterations
+    assert np.array_equal(got.corr_, ref.corr)
+    assert rel_err(got.transformation_, ref.transformation) < TOL
+    assert rel_err(got.fitness_, ref.fitness) < TOL and rel_err(got.inlier_rmse_, ref.inlier_rmse) < TOL
+    # and it differs from plain point-to-plane (the photometric rows matter)
+    p2l = oracle.registration_icp(sc["source"], sc["target"], r, None, 2, nrm, max_iter=20)
+    assert rel_err(ref.transformation, p2l.transformation) > 1e-7
+
+
+def test_colored_icp_edge_cases(ctx, oracle):
+    geometry, reg = _reg()
+    from open3d_amd import _lib
+    sc = _colored_scene(2000, 2200, cfg_id=5)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    src_c = geometry.PointCloud(sc["source"], colors=sc["source_colors"])
+    tgt_c = geometry.PointCloud(sc["target"], normals=nrm, colors=sc["target_colors"])
+    with pytest.raises(_lib.O3DError) as ei:
+        reg.RegistrationColoredICP(src_c, tgt_c, 0.0, ctx=ctx)
+    assert ei.value.status == 1
+    with pytest.raises(_lib.O3DError) as ei:
+        reg.RegistrationColoredICP(src_c, geometry.PointCloud(sc["target"], colors=sc["target_colors"]), 2 * s, ctx=ctx)
+    assert ei.value.status == 2
+    # without colours every update is the identity (ColoredICP.cpp:127-128): the result of the initial search, one iteration
+    got = reg.RegistrationColoredICP(geometry.PointCloud(sc["source"]), tgt_c, 2 * s, ctx=ctx)
+    corr, nc, fit, rmse = oracle.evaluate_registration(sc["source"], sc["target"], 2 * s)
+    assert np.array_equal(got.transformation_, np.eye(4)) and got.iterations_ == 1
+    assert np.array_equal(got.corr_, corr) and got.fitness_ == fit
+    # lambda outside [0, 1] falls back to 0.968 (:50-53)
+    a = reg.RegistrationColoredICP(src_c, tgt_c, 2 * s, lambda_geometric=7.0, ctx=ctx)
+    b = reg.RegistrationColoredICP(src_c, tgt_c, 2 * s, lambda_geometric=0.968, ctx=ctx)
+    assert np.array_equal(a.transformation_, b.transformation_)
