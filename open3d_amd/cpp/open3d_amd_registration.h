@@ -456,6 +456,28 @@ inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, c
   return result;
 }
 
+// RegistrationColoredICP, ColoredICP.cpp:205-211 (colour gradients :68-123 and the two-row estimation :125-177 on the device)
+inline RegistrationResult RegistrationColoredICP(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                                 double max_distance, const o3d_types::Mat4 &init = o3d_types::Mat4::Identity(),
+                                                 const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria(),
+                                                 double lambda_geometric = 0.968, Context &c = Context::Default()) {
+  RegistrationResult result(init);
+  std::vector<int32_t> corr(source.points_.size());
+  int64_t nc = 0;
+  int iters = 0;
+  double T[16];
+  Check(c.get(), o3d_registration_colored_icp(
+                     c.get(), (const double *)source.points_.data(), source.HasColors() ? (const double *)source.colors_.data() : nullptr,
+                     (int64_t)source.points_.size(), (const double *)target.points_.data(),
+                     target.HasNormals() ? (const double *)target.normals_.data() : nullptr,
+                     target.HasColors() ? (const double *)target.colors_.data() : nullptr, (int64_t)target.points_.size(), max_distance,
+                     init.data(), lambda_geometric, criteria.relative_fitness_, criteria.relative_rmse_, criteria.max_iteration_,
+                     O3D_MEM_HOST, T, corr.data(), &nc, &result.fitness_, &result.inlier_rmse_, &iters, nullptr));
+  for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
+  detail::ExpandCorrespondences(corr, result.correspondence_set_);
+  return result;
+}
+
 // GetInformationMatrixFromPointClouds, Registration.cpp:303-355
 inline o3d_types::Mat6 GetInformationMatrixFromPointClouds(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                                            double max_correspondence_distance,

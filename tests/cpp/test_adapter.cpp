@@ -5,7 +5,7 @@
 //   out: p2plane {T[16], fitness, rmse, n_pairs, pairs[2*n_pairs] as double}, evaluate {fitness, rmse, n_pairs},
 //        voxel {m, pts[3m]}, normals(knn 30) {n, nrm[3n]}, error flags {3 doubles}, information matrix {36},
 //        host-estimation ICP (user subclass) {T[16], fitness, rmse, n_pairs, virtual calls}, ComputeRMSE {p2p, p2plane},
-//        batch of two pairs {T[16], fitness, rmse} x 2
+//        batch of two pairs {T[16], fitness, rmse} x 2, coloured ICP with synthetic colours {T[16], fitness, rmse}
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -111,6 +111,16 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 16; i++) put(out, x.transformation_.m[i]);
     put(out, x.fitness_); put(out, x.inlier_rmse_);
   }
+
+  // colours: a fixed function of the point (the Python side builds the same arrays)
+  geometry::PointCloud cs = source, ct = target;
+  cs.colors_.resize(ns);
+  ct.colors_.resize(nt);
+  for (int64_t i = 0; i < ns; i++) { const auto &p = cs.points_[i]; cs.colors_[i] = Vector3d(0.5 + 0.4 * std::sin(2.0 * p(0)), 0.5 + 0.4 * std::cos(1.5 * p(1)), 0.5); }
+  for (int64_t i = 0; i < nt; i++) { const auto &p = ct.points_[i]; ct.colors_[i] = Vector3d(0.5 + 0.4 * std::sin(2.0 * p(0)), 0.5 + 0.4 * std::cos(1.5 * p(1)), 0.5); }
+  reg::RegistrationResult cr = reg::RegistrationColoredICP(cs, ct, radius);
+  for (int i = 0; i < 16; i++) put(out, cr.transformation_.m[i]);
+  put(out, cr.fitness_); put(out, cr.inlier_rmse_);
 
   f = fopen(argv[2], "wb");
   if (!f) return 7;

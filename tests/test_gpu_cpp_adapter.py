@@ -72,4 +72,12 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
         assert np.array_equal(out[o:o + 16].reshape(4, 4).T, w.transformation_)
         assert out[o + 16] == w.fitness_ and out[o + 17] == w.inlier_rmse_
         o += 18
+    def col(p):
+        return np.stack([0.5 + 0.4 * np.sin(2.0 * p[:, 0]), 0.5 + 0.4 * np.cos(1.5 * p[:, 1]), np.full(len(p), 0.5)], axis=1)
+    cw = reg.RegistrationColoredICP(geometry.PointCloud(sc["source"], colors=col(sc["source"])),
+                                    geometry.PointCloud(sc["target"], normals=nrm, colors=col(sc["target"])), radius, ctx=ctx)
+    # libm sin/cos of the two hosts may differ in the last ulp of a colour: compare at the parity bar
+    assert rel_err(out[o:o + 16].reshape(4, 4).T, cw.transformation_) < 1e-6
+    assert rel_err(out[o + 16], cw.fitness_) < 1e-6 and rel_err(out[o + 17], cw.inlier_rmse_) < 1e-6
+    o += 18
     assert o == len(out)

@@ -266,3 +266,56 @@ def test_information_matrix(oracle):
         for row in ([0, z, -y, 1, 0, 0], [-z, 0, x, 0, 1, 0], [y, -x, 0, 0, 0, 1]):  # Registration.cpp:326-346
             want += np.outer(row, row)
     assert np.allclose(G, want, rtol=1e-12)
+
+
+def test_colored_icp_pieces_vs_numpy(oracle):
+    """ColoredICP.cpp:68-177 restated in numpy from the formulas (lstsq with the orthogonality row; explicit 2-row Jacobian)."""
+    sc = make_scene(1500, 1800, cfg_id=303)
+    s = sc["spacing"]
+    tgt, src = sc["target"], sc["source"]
+    nrm = oracle.estimate_normals(tgt, oracle.HYBRID, 30, 4 * s)
+    rng = np.random.default_rng(5)
+    tcol = 0.5 + 0.3 * np.stack([np.sin(2 * tgt[:, 0]), np.cos(1.5 * tgt[:, 1]), np.sin(tgt[:, 0] + tgt[:, 1])], 1)
+    scol = rng.uniform(0.2, 0.8, (len(src), 3))
+    radius = 5 * s
+    grad = oracle.color_gradient(tgt, nrm, tcol, radius, 30)
+    it = tcol.sum(1) / 3.0
+    thr = oracle.radius_threshold(radius)
+    checked = 0
+    for k in rng.integers(0, len(tgt), 60):
+        d2 = ((tgt - tgt[k]) ** 2).sum(1)
+        order = np.lexsort((np.arange(len(tgt)), d2))
+        order = order[d2[order] < thr][:30]
+        if len(order) < 4:
+            assert not grad[k].any()
+            continue
+        nn = len(order)
+        adj = order[1:]
+        proj = tgt[adj] - ((tgt[adj] - tgt[k]) @ nrm[k])[:, None] * nrm[k]
+        A = np.vstack([proj - tgt[k], (nn - 1) * nrm[k]])
+        b = np.concatenate([it[adj] - it[k], [0.0]])
+        x = np.linalg.solve(A.T @ A, A.T @ b)
+        assert np.allclose(grad[k], x, rtol=1e-8, atol=1e-10 * np.abs(x).max())
+        checked += 1
+    assert checked > 30
+
+    corr = oracle.correspondences(src, tgt, 3 * s)[0]
+    lam = 0.9
+    T, JTJ, JTr = oracle.colored_compute(src, scol, tgt, nrm, tcol, grad, corr, lam)
+    J_all, r_all = [], []
+    slg, slp = np.sqrt(lam), np.sqrt(1 - lam)
+    for i in np.nonzero(corr >= 0)[0]:
+        t = corr[i]
+        vs, vt, nt, dit = src[i], tgt[t], nrm[t], grad[t]
+        J_all.append(slg * np.concatenate([np.cross(vs, nt), nt]))
+        r_all.append(slg * (vs - vt) @ nt)
+        vs_proj = vs - ((vs - vt) @ nt) * nt
+        is0 = dit @ (vs_proj - vt) + it[t]
+        ditM = -dit @ (np.eye(3) - np.outer(nt, nt))
+        J_all.append(slp * np.concatenate([np.cross(vs, ditM), ditM]))
+        r_all.append(slp * (scol[i].sum() / 3.0 - is0))
+    J, r = np.array(J_all), np.array(r_all)
+    assert np.allclose(JTJ, J.T @ J, rtol=1e-10) and np.allclose(JTr, J.T @ r, rtol=1e-9, atol=1e-12)
+    x = np.linalg.solve(J.T @ J, -(J.T @ r))
+    assert np.allclose(T, oracle.vec6_to_mat4(x), rtol=1e-8, atol=1e-12)
+    assert np.isclose(oracle.colored_rmse(src, scol, tgt, nrm, tcol, grad, corr, lam), (r * r).sum(), rtol=1e-10)
