@@ -217,6 +217,23 @@ O3D_API int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double 
 O3D_API int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                          double *normals, int has_normals);
 
+/* ---- the other KDTreeFlann consumers on point clouds ------ */
+
+/* PointCloud::ComputePointCloudDistance, geometry/PointCloud.cpp:112-132: out_dist[i] = distance from source point i to its
+ * nearest target point (SearchKNN k = 1, no radius), 0 when the target is empty. */
+O3D_API int o3d_compute_point_cloud_distance(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                                     int mem, double *out_dist);
+/* PointCloud::ComputeNearestNeighborDistance, geometry/PointCloud.cpp:521-544: distance to the second of SearchKNN(k = 2)
+ * on the cloud itself (the first is the point itself), all zero for fewer than 2 points. */
+O3D_API int o3d_compute_nearest_neighbor_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int mem, double *out_dist);
+/* The per-point part of PointCloud::RemoveRadiusOutliers, geometry/PointCloud.cpp:406-411: out_count[i] = SearchRadius
+ * neighbour count (d2 < (double)(float)(r * r), the point itself included); the caller keeps count > nb_points. */
+O3D_API int o3d_radius_neighbor_count(o3d_ctx *ctx, const double *xyz, int64_t n, double search_radius, int mem, int32_t *out_count);
+/* The per-point part of PointCloud::RemoveStatisticalOutliers, geometry/PointCloud.cpp:438-449: out_mean[i] = mean of the
+ * distances to the nb_neighbors nearest points (the point itself included, ascending order), -1 when there is none; the
+ * cloud statistics and the threshold (:453-466) are a serial pass over these values on the caller's side. */
+O3D_API int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_neighbors, int mem, double *out_mean);
+
 #ifdef __cplusplus
 }
 #endif

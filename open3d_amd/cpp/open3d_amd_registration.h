@@ -207,6 +207,59 @@ inline void EstimateNormals(o3d_types::PointCloud &cloud, const o3d_types::KDTre
                                       O3D_MEM_HOST, (double *)cloud.normals_.data(), has ? 1 : 0));
 }
 
+// The other KDTreeFlann consumers on point clouds, geometry/PointCloud.cpp:112-132, 394-468, 521-544.
+inline std::vector<double> ComputePointCloudDistance(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                                     Context &c = Context::Default()) {
+  std::vector<double> d(source.points_.size());
+  Check(c.get(), o3d_compute_point_cloud_distance(c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                                                  (const double *)target.points_.data(), (int64_t)target.points_.size(), O3D_MEM_HOST,
+                                                  d.data()));
+  return d;
+}
+inline std::vector<double> ComputeNearestNeighborDistance(const o3d_types::PointCloud &cloud, Context &c = Context::Default()) {
+  std::vector<double> d(cloud.points_.size(), 0.0);
+  if (cloud.points_.size() < 2) return d;  // :522-524
+  Check(c.get(), o3d_compute_nearest_neighbor_distance(c.get(), (const double *)cloud.points_.data(), (int64_t)cloud.points_.size(),
+                                                       O3D_MEM_HOST, d.data()));
+  return d;
+}
+// indices kept by RemoveRadiusOutliers (:394-419); the caller's SelectByIndex builds the cloud
+inline std::vector<size_t> RadiusOutlierInliers(const o3d_types::PointCloud &cloud, size_t nb_points, double search_radius,
+                                                Context &c = Context::Default()) {
+  if (nb_points < 1 || search_radius <= 0)
+    throw std::runtime_error("[Open3D ERROR] [RemoveRadiusOutliers] Illegal input parameters,number of points and radius must be positive");
+  std::vector<int32_t> cnt(cloud.points_.size());
+  Check(c.get(), o3d_radius_neighbor_count(c.get(), (const double *)cloud.points_.data(), (int64_t)cloud.points_.size(), search_radius,
+                                           O3D_MEM_HOST, cnt.data()));
+  std::vector<size_t> indices;
+  for (size_t i = 0; i < cnt.size(); i++)
+    if ((size_t)cnt[i] > nb_points) indices.push_back(i);
+  return indices;
+}
+// indices kept by RemoveStatisticalOutliers (:421-468): k-nearest mean distances from the device, then the reference's
+// serial statistics (:453-466)
+inline std::vector<size_t> StatisticalOutlierInliers(const o3d_types::PointCloud &cloud, size_t nb_neighbors, double std_ratio,
+                                                     Context &c = Context::Default()) {
+  if (nb_neighbors < 1 || std_ratio <= 0)
+    throw std::runtime_error("[Open3D ERROR] [RemoveStatisticalOutliers] Illegal input parameters, number of neighbors and standard deviation ratio must be positive");
+  std::vector<size_t> indices;
+  if (cloud.points_.empty()) return indices;
+  std::vector<double> avg(cloud.points_.size());
+  Check(c.get(), o3d_knn_mean_distance(c.get(), (const double *)cloud.points_.data(), (int64_t)cloud.points_.size(), (int)nb_neighbors,
+                                       O3D_MEM_HOST, avg.data()));
+  size_t valid = 0;
+  double cloud_mean = 0.0;
+  for (double a : avg) { if (a >= 0) valid++; if (a > 0) cloud_mean += a; }
+  if (valid == 0) return indices;
+  cloud_mean /= (double)valid;
+  double sq_sum = 0.0;
+  for (double a : avg) if (a > 0) sq_sum += (a - cloud_mean) * (a - cloud_mean);
+  const double thr = cloud_mean + std_ratio * std::sqrt(sq_sum / (double)(valid - 1));
+  for (size_t i = 0; i < avg.size(); i++)
+    if (avg[i] > 0 && avg[i] < thr) indices.push_back(i);
+  return indices;
+}
+
 #ifndef O3D_AMD_USE_OPEN3D_TYPES
 inline std::shared_ptr<geometry::PointCloud> geometry::PointCloud::VoxelDownSample(double voxel_size) const {
   return open3d_amd::VoxelDownSample(*this, voxel_size);

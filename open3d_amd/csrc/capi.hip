@@ -30,6 +30,9 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
 int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                               double *normals, int has_normals);
 
+int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int64_t n_cloud, const double *q_xyz, int64_t n_q,
+                            int knn, double radius, int mem, double *out, int32_t *out_count);
+
 static thread_local std::string g_err_noctx;
 
 int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...) {
@@ -787,6 +790,35 @@ int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_
   O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
+}
+
+int o3d_compute_point_cloud_distance(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt, int mem,
+                                     double *out_dist) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_neighbor_query_impl(ctx, 0, tgt_xyz, n_tgt, src_xyz, n_src, 1, 0.0, mem, out_dist, nullptr);
+}
+
+int o3d_compute_nearest_neighbor_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int mem, double *out_dist) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_neighbor_query_impl(ctx, 0, xyz, n, xyz, n, 2, 0.0, mem, out_dist, nullptr);
+}
+
+int o3d_radius_neighbor_count(o3d_ctx *ctx, const double *xyz, int64_t n, double search_radius, int mem, int32_t *out_count) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_neighbor_query_impl(ctx, 2, xyz, n, xyz, n, 1, search_radius, mem, nullptr, out_count);
+}
+
+int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_neighbors, int mem, double *out_mean) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_neighbor_query_impl(ctx, 1, xyz, n, xyz, n, nb_neighbors, 0.0, mem, out_mean, nullptr);
 }
 
 }  // extern "C"

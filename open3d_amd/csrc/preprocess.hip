@@ -495,6 +495,90 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
   }
 }
 
+// The other KDTreeFlann consumers on point clouds (geometry/PointCloud.cpp:112-132, 394-468, 521-544): per query point
+//   MODE 0  sqrt of the knn-th smallest d2 over the grid's cloud, 0 when fewer exist (ComputePointCloudDistance: knn 1 on
+//           another cloud; ComputeNearestNeighborDistance: knn 2 on the cloud itself)
+//   MODE 1  mean of sqrt(d2) over the knn nearest in ascending order, -1 when there is none (RemoveStatisticalOutliers)
+//   MODE 2  number of points with d2 < thr (RemoveRadiusOutliers; the grid's cell size is the radius)
+// Queries are 3 doubles per point in the caller's order; out[i] belongs to query i.
+template <int MODE>
+__global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                                               GridParams gp, const double *__restrict__ q_xyz, int64_t n_q, int knn,
+                                                               double thr, double *__restrict__ out, int32_t *__restrict__ out_count) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  KList l;
+  l.d2 = reinterpret_cast<double *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.idx = l.pos + kNrmBlock * (size_t)knn;
+  l.cap = knn;
+  l.thr = INFINITY;
+  const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
+  for (int64_t i = (int64_t)blockIdx.x * kNrmBlock + lane; i < n_q; i += (int64_t)gridDim.x * kNrmBlock) {
+    const double qx = q_xyz[3 * i], qy = q_xyz[3 * i + 1], qz = q_xyz[3 * i + 2];
+    // a query outside the grid searches from the nearest cell: every point beyond shell R of that cell is still at
+    // least R cells away from the query, which lies on the far side of the cell
+    const int cx = min(max(o3d_cell_coord(qx, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    const int cy = min(max(o3d_cell_coord(qy, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    l.count = 0;
+    int count = 0;
+    for (int R = 1;; R++) {
+      for (int dz = -R; dz <= R; dz++) {
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= gp.nz) continue;
+        for (int dy = -R; dy <= R; dy++) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= gp.ny) continue;
+          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+          const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
+          const int nseg = face ? 1 : 2;
+          for (int sgi = 0; sgi < nseg; sgi++) {
+            int xa, xb;
+            if (face) { xa = cx - R; xb = cx + R; }
+            else if (sgi == 0) { xa = xb = cx - R; }
+            else { xa = xb = cx + R; }
+            xa = max(xa, -1); xb = min(xb, gp.nx);
+            if (xa > xb) continue;
+            const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+            for (uint32_t j = s; j < e; j++) {
+              const double4 t = pts[j];
+              const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
+              double d2 = ddx * ddx;
+              d2 = d2 + ddy * ddy;
+              d2 = d2 + ddz * ddz;
+              if (MODE == 2) {
+                if (d2 < thr) count++;
+              } else if (d2 <= klist_worst(l)) {
+                klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+              }
+            }
+          }
+        }
+      }
+      if (MODE == 2) break;  // h >= radius: the 3x3x3 block is complete
+      if (R >= max_dim) break;
+      if (l.count == l.cap) {
+        const double reach = (double)R * gp.h * (1.0 - 1e-6);
+        if (klist_worst(l) <= reach * reach) break;
+      }
+    }
+    if (MODE == 0) {
+      out[i] = (l.count >= knn) ? sqrt(l.d2[(knn - 1) * kNrmBlock]) : 0.0;
+    } else if (MODE == 1) {
+      double mean = -1.0;
+      if (l.count > 0) {
+        double sum = 0.0;  // std::accumulate over the ascending distances (PointCloud.cpp:445-446)
+        for (int k = 0; k < l.count; k++) sum += sqrt(l.d2[k * kNrmBlock]);
+        mean = sum / (double)l.count;
+      }
+      out[i] = mean;
+    } else {
+      out_count[i] = count;
+    }
+  }
+}
+
 // Non-finite points are not in the grid: FLANN finds no finite-distance neighbour for them -> fewer than 3 -> (0,0,1).
 __global__ __launch_bounds__(O3D_BLOCK) void k_normals_nonfinite(const double *__restrict__ xyz, int64_t n, double *__restrict__ normals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -526,6 +610,28 @@ static int count_occupied_cells(o3d_ctx *ctx, int64_t n, int64_t *out) {
   O3D_HIP(ctx, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = (int64_t)*h;
+  return O3D_OK;
+}
+
+// Grid for k-nearest-neighbour queries over a cloud: cell size from the cloud's density, aiming at ~8 points per
+// occupied cell (at most four trial builds).  Leaves the grid built; *out_h is the cell size asked for last.
+static int build_knn_grid(o3d_ctx *ctx, const double *d_xyz, int64_t n, double *out_h) {
+  double bb[6];
+  int64_t nf = 0;
+  O3D_TRY(o3d_bounds(ctx, d_xyz, n, bb, &nf));
+  const double ext = std::max(std::max(bb[3] - bb[0], bb[4] - bb[1]), std::max(bb[5] - bb[2], 1e-300));
+  double h = ext * sqrt(8.0 / (double)std::max<int64_t>(nf, 1));
+  if (!(h > 0.0)) h = 1.0;
+  for (int trial = 0; trial < 4 && nf > 0; trial++) {
+    O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, h));
+    int64_t occ = 0;
+    O3D_TRY(count_occupied_cells(ctx, n, &occ));
+    const double pop = (double)nf / (double)std::max<int64_t>(occ, 1);
+    if (pop >= 4.0 && pop <= 16.0) break;
+    if (ctx->gp.h > h * 1.01 && pop > 16.0) break;  // the dense-table budget already coarsened the grid
+    h = ctx->gp.h / (1.0 + 1e-5) * pow(8.0 / pop, 1.0 / 2.5);
+  }
+  *out_h = h;
   return O3D_OK;
 }
 
@@ -561,22 +667,7 @@ int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int se
       return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: knn/max_nn > %d is not on the device path", kMaxKnn);
     double h;
     if (search_type == O3D_SEARCH_KNN) {
-      // cell size from the cloud's density: aim at ~8 points per occupied cell (two trial builds at most four times)
-      double bb[6];
-      int64_t nf = 0;
-      O3D_TRY(o3d_bounds(ctx, d_xyz, n, bb, &nf));
-      const double ext = std::max(std::max(bb[3] - bb[0], bb[4] - bb[1]), std::max(bb[5] - bb[2], 1e-300));
-      h = ext * sqrt(8.0 / (double)std::max<int64_t>(nf, 1));
-      if (!(h > 0.0)) h = 1.0;
-      for (int trial = 0; trial < 4 && nf > 0; trial++) {
-        O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, h));
-        int64_t occ = 0;
-        O3D_TRY(count_occupied_cells(ctx, n, &occ));
-        const double pop = (double)nf / (double)std::max<int64_t>(occ, 1);
-        if (pop >= 4.0 && pop <= 16.0) break;
-        if (ctx->gp.h > h * 1.01 && pop > 16.0) break;  // the dense-table budget already coarsened the grid
-        h = ctx->gp.h / (1.0 + 1e-5) * pow(8.0 / pop, 1.0 / 2.5);
-      }
+      O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h));
     } else {
       h = radius;
     }
@@ -744,4 +835,72 @@ int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_n
                      max_nn, thr, d_nrm, d_col, d_grad);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
+}
+
+// mode 0: knn-th neighbour distance, 1: mean knn distance, 2: radius count (see k_neighbor_query).  cloud = the points
+// searched (n_cloud), q = the queries (n_q; may be the same buffer).  Outputs in `mem` space.
+int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int64_t n_cloud, const double *q_xyz, int64_t n_q,
+                            int knn, double radius, int mem, double *out, int32_t *out_count) {
+  if (n_cloud < 0 || n_q < 0 || (n_cloud > 0 && !cloud_xyz) || (n_q > 0 && (!q_xyz || (mode == 2 ? !out_count : !out))))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "neighbour query: bad sizes or null buffers");
+  if (n_cloud >= ((int64_t)1 << 31) || n_q >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "more than 2^31-1 points");
+  if (mode != 2 && (knn < 1 || knn > kMaxKnn))
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "neighbour query: knn must be in [1, %d] on the device path", kMaxKnn);
+  if (mode == 2 && !(radius > 0.0)) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "neighbour query: radius must be positive");
+  if (n_q == 0) return O3D_OK;
+  ctx->icp_ready = 0;  // the context's grid is rebuilt
+  const bool same = (q_xyz == cloud_xyz);
+  const double *d_cloud = cloud_xyz, *d_q = q_xyz;
+  void *sc = nullptr, *sq = nullptr, *so = nullptr;
+  const size_t out_bytes = (mode == 2 ? sizeof(int32_t) : sizeof(double)) * (size_t)n_q;
+  auto cleanup = [&]() {
+    if (sc) (void)hipFree(sc);
+    if (sq) (void)hipFree(sq);
+    if (so) (void)hipFree(so);
+  };
+  auto run = [&]() -> int {
+    void *d_out = (mode == 2) ? (void *)out_count : (void *)out;
+    if (mem == O3D_MEM_HOST) {
+      if (n_cloud > 0) {
+        O3D_HIP(ctx, hipMalloc(&sc, sizeof(double) * 3 * (size_t)n_cloud));
+        O3D_HIP(ctx, hipMemcpyAsync(sc, cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud, hipMemcpyHostToDevice, ctx->stream));
+        d_cloud = (const double *)sc;
+      }
+      if (same) {
+        d_q = d_cloud;
+      } else {
+        O3D_HIP(ctx, hipMalloc(&sq, sizeof(double) * 3 * (size_t)n_q));
+        O3D_HIP(ctx, hipMemcpyAsync(sq, q_xyz, sizeof(double) * 3 * (size_t)n_q, hipMemcpyHostToDevice, ctx->stream));
+        d_q = (const double *)sq;
+      }
+      O3D_HIP(ctx, hipMalloc(&so, out_bytes));
+      d_out = so;
+    }
+    double h = radius;
+    if (mode == 2) O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, n_cloud, radius));
+    else if (n_cloud > 0) O3D_TRY(build_knn_grid(ctx, d_cloud, n_cloud, &h));
+    else O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, 0, 1.0));
+    const int kk = (mode == 2) ? 1 : knn;
+    const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)kk;
+    int64_t g = (n_q + kNrmBlock - 1) / kNrmBlock;
+    g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+    const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126
+    if (mode == 0)
+      hipLaunchKernelGGL(k_neighbor_query<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ctx->cell_start, ctx->gp,
+                         d_q, n_q, kk, thr, (double *)d_out, (int32_t *)nullptr);
+    else if (mode == 1)
+      hipLaunchKernelGGL(k_neighbor_query<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ctx->cell_start, ctx->gp,
+                         d_q, n_q, kk, thr, (double *)d_out, (int32_t *)nullptr);
+    else
+      hipLaunchKernelGGL(k_neighbor_query<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ctx->cell_start, ctx->gp,
+                         d_q, n_q, kk, thr, (double *)nullptr, (int32_t *)d_out);
+    O3D_HIP(ctx, hipGetLastError());
+    if (mem == O3D_MEM_HOST)
+      O3D_HIP(ctx, hipMemcpyAsync(mode == 2 ? (void *)out_count : (void *)out, so, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return O3D_OK;
+  };
+  const int st = run();
+  cleanup();
+  return st;
 }

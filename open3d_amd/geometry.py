@@ -98,3 +98,67 @@ class PointCloud:
                                                 _lib.MEM_HOST, _lib.ptr(nrm), int(has)))
         self.normals_ = nrm
         return self
+
+    def SelectByIndex(self, indices):
+        """PointCloud::SelectByIndex (points, normals, colours of the listed indices, in that order)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        return PointCloud(self.points_[idx], self.normals_[idx] if self.HasNormals() else None,
+                          self.colors_[idx] if self.HasColors() else None)
+
+    def ComputePointCloudDistance(self, target, ctx=None):
+        """PointCloud::ComputePointCloudDistance, geometry/PointCloud.cpp:112-132."""
+        ctx = ctx or _lib.default_context()
+        out = np.zeros(len(self.points_))
+        ctx.check(ctx._lib.o3d_compute_point_cloud_distance(ctx.handle, _lib.ptr(self.points_), len(self.points_),
+                                                            _lib.ptr(target.points_), len(target.points_), _lib.MEM_HOST,
+                                                            _lib.ptr(out)))
+        return out
+
+    def ComputeNearestNeighborDistance(self, ctx=None):
+        """PointCloud::ComputeNearestNeighborDistance, geometry/PointCloud.cpp:521-544."""
+        ctx = ctx or _lib.default_context()
+        out = np.zeros(len(self.points_))
+        if len(self.points_) < 2:
+            return out
+        ctx.check(ctx._lib.o3d_compute_nearest_neighbor_distance(ctx.handle, _lib.ptr(self.points_), len(self.points_),
+                                                                 _lib.MEM_HOST, _lib.ptr(out)))
+        return out
+
+    def RemoveRadiusOutliers(self, nb_points, search_radius, ctx=None):
+        """PointCloud::RemoveRadiusOutliers, geometry/PointCloud.cpp:394-419 -> (cloud, indices)."""
+        if nb_points < 1 or not (search_radius > 0):
+            raise _lib.O3DError(5, "[Open3D ERROR] [RemoveRadiusOutliers] Illegal input parameters,"
+                                   "number of points and radius must be positive")
+        ctx = ctx or _lib.default_context()
+        cnt = np.zeros(max(len(self.points_), 1), np.int32)
+        ctx.check(ctx._lib.o3d_radius_neighbor_count(ctx.handle, _lib.ptr(self.points_), len(self.points_), float(search_radius),
+                                                     _lib.MEM_HOST, _lib.ptr(cnt)))
+        indices = np.nonzero(cnt[: len(self.points_)] > nb_points)[0]
+        return self.SelectByIndex(indices), indices
+
+    def RemoveStatisticalOutliers(self, nb_neighbors, std_ratio, ctx=None):
+        """PointCloud::RemoveStatisticalOutliers, geometry/PointCloud.cpp:421-468 -> (cloud, indices).  The k-nearest mean
+        distances come from the device; the cloud statistics are the reference's serial sums (:453-461)."""
+        if nb_neighbors < 1 or not (std_ratio > 0):
+            raise _lib.O3DError(5, "[Open3D ERROR] [RemoveStatisticalOutliers] Illegal input parameters, number "
+                                   "of neighbors and standard deviation ratio must be positive")
+        n = len(self.points_)
+        if n == 0:
+            return PointCloud(), np.zeros(0, np.int64)
+        ctx = ctx or _lib.default_context()
+        avg = np.zeros(n)
+        ctx.check(ctx._lib.o3d_knn_mean_distance(ctx.handle, _lib.ptr(self.points_), n, int(nb_neighbors), _lib.MEM_HOST,
+                                                 _lib.ptr(avg)))
+        valid = int(np.count_nonzero(avg >= 0))  # mean = -1 marks "no neighbour" (:442-448)
+        if valid == 0:
+            return PointCloud(), np.zeros(0, np.int64)
+        pos = avg > 0
+        cloud_mean = float(np.cumsum(avg[pos])[-1]) / valid if pos.any() else 0.0  # sequential sum, as std::accumulate
+        dev = avg[pos] - cloud_mean
+        sq_sum = float(np.cumsum(dev * dev)[-1]) if pos.any() else 0.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            std_dev = float(np.sqrt(np.float64(sq_sum) / np.float64(valid - 1)))
+        thr = cloud_mean + std_ratio * std_dev
+        indices = np.nonzero((avg > 0) & (avg < thr))[0]
+        return self.SelectByIndex(indices), indices
+

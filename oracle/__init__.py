@@ -264,6 +264,16 @@ def registration_colored_icp(src, src_col, tgt, tgt_nrm, tgt_col, max_dist, init
     return r
 
 
+def neighbor_query(mode, cloud, queries, knn=1, radius=0.0):
+    """PointCloud.cpp:112-132 (mode 0, knn 1), :521-544 (mode 0, knn 2 on itself), :438-449 (mode 1), :406-411 (mode 2)."""
+    cloud, queries = _pts(cloud), _pts(queries)
+    out = np.zeros(len(queries))
+    cnt = np.zeros(max(len(queries), 1), np.int32)
+    lib().orc_neighbor_query(int(mode), _d(cloud), C.c_int64(len(cloud)), _d(queries), C.c_int64(len(queries)), int(knn),
+                             C.c_double(radius), _d(out), _i(cnt))
+    return cnt[: len(queries)] if mode == 2 else out
+
+
 def voxel_down_sample(pts, voxel, normals=None, colors=None):
     """PointCloud.cpp:273-306 -> (points, normals|None, colors|None, voxel_index int32[M,3]); sorted by (z,y,x)."""
     pts = _pts(pts)

@@ -1003,6 +1003,52 @@ ORC_EXPORT int orc_registration_colored_icp(const double *src, const double *src
   return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* The other KDTreeFlann consumers, geometry/PointCloud.cpp:112-132,394-468,521-544 */
+/* mode 0: sqrt of the knn-th smallest d2 (0 when fewer), 1: mean of the knn       */
+/* distances (-1 when none), 2: SearchRadius count.                                */
+/* ------------------------------------------------------------------------- */
+ORC_EXPORT void orc_neighbor_query(int mode, const double *cloud, int64_t nc, const double *q, int64_t nq, int knn, double radius,
+                                   double *out, int32_t *out_count) {
+  orc_kdtree *kd = orc_kdtree_build(cloud, nc);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(knn > 0 ? knn : 1));
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)(knn > 0 ? knn : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < nq; i++) {
+      if (mode == 2) {
+        int *ri = NULL;
+        double *rd = NULL;
+        const int k = nc > 0 ? orc_kdtree_search_radius(kd, q + 3 * i, radius, &ri, &rd) : 0;
+        out_count[i] = k > 0 ? k : 0;
+        free(ri);
+        free(rd);
+        continue;
+      }
+      const int k = nc > 0 ? orc_kdtree_search_knn(kd, q + 3 * i, knn, idx, d2) : 0;
+      if (mode == 0) {
+        out[i] = (k >= knn) ? sqrt(d2[knn - 1]) : 0.0;
+      } else {
+        double mean = -1.0;
+        if (k > 0) {
+          double sum = 0.0;
+          for (int j = 0; j < k; j++) sum += sqrt(d2[j]);
+          mean = sum / (double)k;
+        }
+        out[i] = mean;
+      }
+    }
+    free(idx);
+    free(d2);
+  }
+  orc_kdtree_free(kd);
+}
+
 /* EvaluateRegistration, Registration.cpp:118-127 */
 ORC_EXPORT int orc_evaluate_registration(const double *src, int64_t ns, const double *tgt, int64_t nt, double max_dist,
                                          const double *T, int use_brute, int32_t *corr_out, int64_t *n_corr, double *fitness,

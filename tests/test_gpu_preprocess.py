@@ -138,3 +138,66 @@ def test_pipeline_downsample_normals_icp(ctx, oracle):
     assert got.iterations_ == ref.iterations
     assert np.array_equal(got.corr_, ref.corr)
     assert np.max(np.abs(got.transformation_ - ref.transformation)) < 1e-6
+
+
+def test_point_cloud_distances_match_oracle(ctx, oracle):
+    """ComputePointCloudDistance (PointCloud.cpp:112-132) and ComputeNearestNeighborDistance (:521-544)."""
+    from open3d_amd import geometry
+    sc = make_scene(7000, 9000, cfg_id=71, theta_deg=3.0, tau=(4.0, -2.0, 1.0))
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    # include queries far outside the target's bounding box
+    far = np.vstack([sc["source"], sc["source"][:50] + np.array([30.0, -12.0, 5.0])])
+    got = geometry.PointCloud(far).ComputePointCloudDistance(tgt, ctx=ctx)
+    ref = oracle.neighbor_query(0, sc["target"], far, knn=1)
+    assert np.array_equal(got, ref)
+    got = tgt.ComputeNearestNeighborDistance(ctx=ctx)
+    ref = oracle.neighbor_query(0, sc["target"], sc["target"], knn=2)
+    assert np.array_equal(got, ref) and (got > 0).all()
+    # degenerate sizes
+    assert list(geometry.PointCloud(sc["target"][:1]).ComputeNearestNeighborDistance(ctx=ctx)) == [0.0]
+    assert not src.ComputePointCloudDistance(geometry.PointCloud(), ctx=ctx).any()     # :122-126: no neighbour -> 0
+    dup = geometry.PointCloud(np.repeat(sc["target"][:5], 2, axis=0))
+    assert not dup.ComputeNearestNeighborDistance(ctx=ctx).any()                         # duplicates: distance 0
+
+
+def test_outlier_removal_matches_oracle(ctx, oracle):
+    """RemoveRadiusOutliers (PointCloud.cpp:394-419) and RemoveStatisticalOutliers (:421-468)."""
+    from open3d_amd import geometry, _lib
+    sc = make_scene(100, 12000, cfg_id=72)
+    s = sc["spacing"]
+    rng = np.random.default_rng(8)
+    pts = np.vstack([sc["target"], sc["target"][rng.integers(0, 12000, 300)] + rng.normal(0, 6 * s, (300, 3))])  # + outliers
+    nrm = rng.normal(size=pts.shape)
+    pc = geometry.PointCloud(pts, normals=nrm)
+
+    radius, nb = 2.5 * s, 10
+    cloud, idx = pc.RemoveRadiusOutliers(nb, radius, ctx=ctx)
+    cnt = oracle.neighbor_query(2, pts, pts, radius=radius)
+    want = np.nonzero(cnt > nb)[0]
+    assert np.array_equal(idx, want) and 0 < len(want) < len(pts)
+    assert np.array_equal(cloud.points_, pts[want]) and np.array_equal(cloud.normals_, nrm[want])
+
+    k, ratio = 20, 1.5
+    cloud, idx = pc.RemoveStatisticalOutliers(k, ratio, ctx=ctx)
+    avg = oracle.neighbor_query(1, pts, pts, knn=k)
+    valid = np.count_nonzero(avg >= 0)
+    mean = 0.0
+    for a in avg:  # std::accumulate with the y > 0 filter (:453-455)
+        if a > 0:
+            mean += a
+    mean /= valid
+    sq = 0.0
+    for a in avg:
+        if a > 0:
+            sq += (a - mean) * (a - mean)
+    thr = mean + ratio * np.sqrt(sq / (valid - 1))
+    want = np.nonzero((avg > 0) & (avg < thr))[0]
+    assert np.array_equal(idx, want) and 0 < len(want) < len(pts)
+    assert np.array_equal(cloud.points_, pts[want])
+
+    for bad in ((0, radius), (5, 0.0)):
+        with pytest.raises(_lib.O3DError):
+            pc.RemoveRadiusOutliers(*bad, ctx=ctx)
+    with pytest.raises(_lib.O3DError):
+        pc.RemoveStatisticalOutliers(0, 1.0, ctx=ctx)
+    assert len(geometry.PointCloud().RemoveStatisticalOutliers(5, 1.0, ctx=ctx)[1]) == 0
