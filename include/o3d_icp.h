@@ -97,6 +97,17 @@ O3D_API int o3d_evaluate_registration(o3d_ctx *ctx, const double *src_xyz, int64
                               double max_correspondence_distance, const double transformation_colmajor[16], int mem,
                               int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
 
+/* The validation step of RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:269-275, for a batch of hypotheses:
+ * for each of the n_hyp transformations (16 doubles each, column-major) the source is transformed (always, :269-270) and
+ * GetRegistrationResultAndCorrespondences (:41-91) gives out_fitness[k] / out_inlier_rmse[k] / out_n_corr[k].  The target
+ * grid is built and the source uploaded once.  *out_best = the hypothesis RANSAC keeps (:272-275: highest fitness, then
+ * lowest rmse, the earliest on a tie; -1 when no hypothesis has a correspondence) and out_corr_best (nullable, n_src) its
+ * correspondences. */
+O3D_API int o3d_evaluate_hypotheses(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt,
+                            double max_correspondence_distance, const double *transformations_colmajor, int n_hyp, int mem,
+                            double *out_fitness, double *out_inlier_rmse, int64_t *out_n_corr, int *out_best,
+                            int32_t *out_corr_best);
+
 /* RegistrationColoredICP, pipelines/registration/ColoredICP.cpp:205-211: InitializePointCloudForColoredICP (:68-123, the
  * per-target-point colour gradient over KDTreeSearchParamHybrid(2 * max_distance, 30)) followed by RegistrationICP with
  * TransformationEstimationForColoredICP::ComputeTransformation (:125-177: a geometric and a photometric row per

@@ -33,6 +33,8 @@ _SIGNATURES = {
                                        C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int)]),
     "o3d_evaluate_registration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp,
                                             C.c_int, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp]),
+    "o3d_evaluate_hypotheses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "o3d_registration_colored_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int64, C.c_double, c_dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                                c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp, C.POINTER(C.c_int), C.c_void_p]),

@@ -22,6 +22,7 @@ int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
 int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
                      const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad);
 int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]);
+int o3d_launch_set_hypothesis(o3d_ctx *ctx, const double T[16]);
 int o3d_launch_color_gather(o3d_ctx *ctx, const double *d_tgt_col, const double *d_grad, const double *d_src_col);
 int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double radius,
                             int max_nn, double *d_grad);
@@ -195,6 +196,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   for (int i = 0; i < 7; i++)
     if (ctx->stage.p[i]) (void)hipFree(ctx->stage.p[i]);
+  if (ctx->src_orig) (void)hipFree(ctx->src_orig);
   if (ctx->tcol_sorted) (void)hipFree(ctx->tcol_sorted);
   if (ctx->sint_sorted) (void)hipFree(ctx->sint_sorted);
   for (hipEvent_t e : ctx->prof_ev)
@@ -329,6 +331,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   for (auto &e : ev) (void)hipEventDestroy(e);
   ctx->enq_passes = 0;
   ctx->sums_valid = 0;
+  ctx->hyp_mode = 0;
   ctx->icp_ready = 1;
   return O3D_OK;
 }
@@ -774,6 +777,72 @@ int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, c
     for (int c = 0; c < r; c++) G(r, c) = G(c, r);
 #undef G
   return O3D_OK;
+}
+
+int o3d_evaluate_hypotheses(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt, double max_dist,
+                            const double *Ts, int n_hyp, int mem, double *out_fitness, double *out_rmse, int64_t *out_n_corr,
+                            int *out_best, int32_t *out_corr_best) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (n_hyp < 0 || (n_hyp > 0 && !Ts)) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad hypothesis list");
+  if (out_best) *out_best = -1;
+  if (n_hyp == 0) return O3D_OK;
+  static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (!(max_dist > 0.0)) {  // Registration.cpp:45-47: empty results
+    for (int k = 0; k < n_hyp; k++) {
+      if (out_fitness) out_fitness[k] = 0.0;
+      if (out_rmse) out_rmse[k] = 0.0;
+      if (out_n_corr) out_n_corr[k] = 0;
+    }
+    return O3D_OK;
+  }
+  O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, max_dist, kIdentity, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, mem,
+                        n_src));
+  DeviceGuard guard(ctx->device);
+  const size_t sbytes = sizeof(double) * 3 * (size_t)(n_src > 0 ? n_src : 1);
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->src_orig, &ctx->cap_src_orig, sbytes));
+  if (n_src > 0) O3D_HIP(ctx, hipMemcpyAsync(ctx->src_orig, ctx->src_sorted, sizeof(double) * 3 * (size_t)n_src, hipMemcpyDeviceToDevice, ctx->stream));
+  void *d_all;
+  O3D_TRY(o3d_scratch(ctx, 7, sizeof(double) * O3D_NSUMS * (size_t)n_hyp, &d_all));
+  ctx->hyp_mode = 1;
+  auto run = [&]() -> int {
+    for (int k = 0; k < n_hyp; k++) {  // everything is enqueued; no host round trip per hypothesis
+      O3D_TRY(o3d_launch_set_hypothesis(ctx, Ts + 16 * (size_t)k));
+      O3D_TRY(o3d_icp_pass_to(ctx, (double *)d_all + (size_t)k * O3D_NSUMS));
+    }
+    std::vector<double> h((size_t)n_hyp * O3D_NSUMS);
+    O3D_HIP(ctx, hipMemcpyAsync(h.data(), d_all, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int best = -1;
+    double bf = 0.0, br = 0.0;  // RegistrationResult() starts at fitness 0, rmse 0 (Registration.h:112-113)
+    for (int k = 0; k < n_hyp; k++) {
+      const double nc = h[(size_t)k * O3D_NSUMS + O3D_SUM_NC];
+      const double fit = nc > 0.0 ? nc / (double)n_src : 0.0;
+      const double rm = nc > 0.0 ? sqrt(h[(size_t)k * O3D_NSUMS + O3D_SUM_D2] / nc) : 0.0;
+      if (out_fitness) out_fitness[k] = fit;
+      if (out_rmse) out_rmse[k] = rm;
+      if (out_n_corr) out_n_corr[k] = (int64_t)nc;
+      if (fit > bf || (fit == bf && rm < br)) { bf = fit; br = rm; best = k; }  // :272-275
+    }
+    if (out_best) *out_best = best;
+    if (out_corr_best && n_src > 0) {
+      if (best >= 0) {
+        O3D_TRY(o3d_launch_set_hypothesis(ctx, Ts + 16 * (size_t)best));
+        O3D_TRY(o3d_icp_pass(ctx));
+        O3D_TRY(o3d_icp_fetch(ctx, mem, out_corr_best, nullptr, nullptr, nullptr));
+      } else if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_corr_best, 0xFF, sizeof(int32_t) * (size_t)n_src, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        memset(out_corr_best, 0xFF, sizeof(int32_t) * (size_t)n_src);
+      }
+    }
+    return O3D_OK;
+  };
+  const int st = run();
+  ctx->hyp_mode = 0;
+  ctx->icp_ready = 0;  // the in-place source no longer matches the loop state
+  return st;
 }
 
 int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel_size,

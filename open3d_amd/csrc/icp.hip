@@ -265,7 +265,8 @@ __device__ unsigned long long g_tile_stats[8];
 
 struct PassArgs {
   int stats;
-  double *src;
+  double *src;           // source in processing order: transformed in place (written by the search kernels)
+  const double *src_in;  // where the search kernels read the source from: src, or the untouched copy (hypothesis mode)
   int64_t n_src;
   const double4 *tgt;
   const float4 *tgt_local;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams
   const int64_t beg = (int64_t)chunk * per;
   const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
   for (int64_t i = beg + threadIdx.x; i < end; i += O3D_BLOCK) {
-    double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
+    double x = a.src_in[3 * i], y = a.src_in[3 * i + 1], z = a.src_in[3 * i + 2];
     if (apply) {
       apply_update(T, w, x, y, z);
       a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     const bool valid = i < end;
     double x = 0, y = 0, z = 0;
     if (valid) {
-      x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
+      x = a.src_in[3 * i]; y = a.src_in[3 * i + 1]; z = a.src_in[3 * i + 2];
     }
     if (valid && apply) {
       apply_update(T, w, x, y, z);
@@ -1373,7 +1374,22 @@ __global__ void k_icp_set_update(IcpState *__restrict__ st, Mat16 u) {
   st->iters = st->iters + 1;
 }
 
+// Hypothesis mode (RANSAC validation, Registration.cpp:269-271): the next pass transforms the untouched source by T.
+__global__ void k_icp_set_hypothesis(IcpState *__restrict__ st, Mat16 u) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 16; i++) { st->update[i] = u.m[i]; st->T[i] = u.m[i]; }
+  st->apply_update = 1;
+}
+
 }  // namespace
+
+int o3d_launch_set_hypothesis(o3d_ctx *ctx, const double T[16]) {
+  Mat16 u;
+  for (int i = 0; i < 16; i++) u.m[i] = T[i];
+  hipLaunchKernelGGL(k_icp_set_hypothesis, dim3(1), dim3(64), 0, ctx->stream, ctx->state, u);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
 
 int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out) {
   PassArgs pa{};
@@ -1422,7 +1438,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   }
   PassArgs pa;
   pa.stats = ctx->tile_stats;
-  pa.src = ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
+  pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;

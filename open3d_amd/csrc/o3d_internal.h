@@ -80,6 +80,9 @@ struct o3d_ctx {
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
   unsigned long long *pend_mask = nullptr;  // one bit per processing position: left to k_icp_fixup
   size_t cap_src = 0;
+  double *src_orig = nullptr;      // hypothesis mode: the source in processing order, never transformed
+  size_t cap_src_orig = 0;
+  int hyp_mode = 0;
   // coloured ICP
   double4 *tcol_sorted = nullptr;  // per sorted target point {intensity, colour gradient}
   double *sint_sorted = nullptr;   // per processing position: source intensity

@@ -243,6 +243,31 @@ def RegistrationICPBatch(sources, targets, max_correspondence_distance, inits=No
     return out
 
 
+def EvaluateHypotheses(source, target, max_correspondence_distance, transformations, want_corr=True, ctx=None):
+    """The validation step of RegistrationRANSACBasedOnFeatureMatching (Registration.cpp:269-275) for a list of candidate
+    transformations.  Returns (fitness[k], inlier_rmse[k], best RegistrationResult or None): `best` is the hypothesis
+    RANSAC's comparison keeps."""
+    ctx = ctx or _lib.default_context()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    n = len(transformations)
+    Ts = np.ascontiguousarray(np.stack([_lib.colmajor(T) for T in transformations])) if n else np.zeros((0, 16))
+    fit, rmse, nc = np.zeros(max(n, 1)), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int64)
+    corr = np.empty(max(len(src), 1), np.int32) if want_corr else None
+    best = C.c_int(-1)
+    ctx.check(ctx._lib.o3d_evaluate_hypotheses(ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), len(tgt),
+                                               float(max_correspondence_distance), _lib.ptr(Ts), n, _lib.MEM_HOST, _lib.ptr(fit),
+                                               _lib.ptr(rmse), _lib.ptr(nc), C.byref(best), _lib.ptr(corr)))
+    res = None
+    if best.value >= 0:
+        res = RegistrationResult(np.asarray(transformations[best.value], dtype=np.float64))
+        res.fitness_, res.inlier_rmse_, res.index_ = float(fit[best.value]), float(rmse[best.value]), best.value
+        if want_corr:
+            res.corr_ = corr[: len(src)].copy()
+            res.correspondence_set_ = _pairs(res.corr_)
+    return fit[:n], rmse[:n], res
+
+
 def RegistrationColoredICP(source, target, max_distance, init=None, criteria=None, lambda_geometric=0.968, ctx=None,
                            return_gradients=False):
     """RegistrationColoredICP, ColoredICP.cpp:205-211 (colour gradients :68-123, estimation :125-177), on the device."""

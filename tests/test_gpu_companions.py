@@ -257,3 +257,38 @@ def test_colored_icp_edge_cases(ctx, oracle):
     a = reg.RegistrationColoredICP(src_c, tgt_c, 2 * s, lambda_geometric=7.0, ctx=ctx)
     b = reg.RegistrationColoredICP(src_c, tgt_c, 2 * s, lambda_geometric=0.968, ctx=ctx)
     assert np.array_equal(a.transformation_, b.transformation_)
+
+
+def test_evaluate_hypotheses_matches_oracle(ctx, oracle):
+    """RANSAC's validation step (Registration.cpp:269-275) over a list of candidate transformations."""
+    geometry, reg = _reg()
+    sc = make_scene(9000, 10000, cfg_id=88)
+    s = sc["spacing"]
+    r = 2 * s
+    rng = np.random.default_rng(4)
+    Ts = [np.eye(4), sc["T_true"]]
+    for k in range(10):
+        T = sc["T_true"].copy()
+        T[:3, 3] += rng.normal(0, (k + 1) * 0.5 * s, 3)
+        Ts.append(T)
+    far = np.eye(4)
+    far[:3, 3] = 100.0
+    Ts.append(far)
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    fit, rmse, best = reg.EvaluateHypotheses(src, tgt, r, Ts, ctx=ctx)
+    want_best, bf, br = -1, 0.0, 0.0
+    for k, T in enumerate(Ts):
+        corr, nc, f, e = oracle.evaluate_registration(sc["source"], sc["target"], r, T)
+        assert fit[k] == f and rel_err(rmse[k], e) < 1e-12 if nc else (fit[k] == 0 and rmse[k] == 0)
+        if f > bf or (f == bf and e < br):
+            want_best, bf, br = k, f, e
+    assert fit[-1] == 0.0 and best.index_ == want_best == 1
+    assert np.array_equal(best.corr_, oracle.evaluate_registration(sc["source"], sc["target"], r, Ts[want_best])[0])
+    # the context still serves ordinary calls afterwards
+    ev = reg.EvaluateRegistration(src, tgt, r, sc["T_true"], ctx=ctx)
+    assert ev.fitness_ == fit[1]
+    # degenerate: no hypothesis, invalid distance, nothing matches
+    assert reg.EvaluateHypotheses(src, tgt, r, [], ctx=ctx)[2] is None
+    f0, r0, b0 = reg.EvaluateHypotheses(src, tgt, 0.0, Ts[:3], ctx=ctx)
+    assert not f0.any() and b0 is None
+    assert reg.EvaluateHypotheses(src, tgt, r, [far], ctx=ctx)[2] is None
