@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE configs other than the headline, for DESIGN.md -- not the bench.py line.
+Prints one JSON object per config.  Host buffers (PCIe included) unless stated."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from open3d_amd import _lib, geometry, synthetic
+from open3d_amd.pipelines import registration as reg
+
+ctx = _lib.Context(0)
+dev = torch.device("cuda", 0)
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def timed(fn, reps=1):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / reps, out
+
+
+def device_loop(src, tgt, nrm, r, est, iters):
+    """iterations/s of the device-resident loop with inputs resident in HBM."""
+    d = [torch.from_numpy(a).to(dev) if a is not None else None for a in (src, tgt, nrm)]
+    sess = reg.IcpSession(ctx).setup(d[0], d[1], d[2], r, np.eye(4), est, reg.ICPConvergenceCriteria(0, 0, iters + 4))
+    for _ in range(4):
+        sess.enqueue_step()
+    sess.poll()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        sess.enqueue_step()
+    sess.poll()
+    dt = time.perf_counter() - t0
+    return iters / dt, sess.setup_ms()
+
+
+which = sys.argv[1:] or ["1", "2", "3", "5"]
+
+if "1" in which:  # config 1: point-to-point, 100k x 100k
+    sc = synthetic.make_pair(100_000, 100_000, cfg_id=1, theta_deg=0.05, tau_in_spacings=(1.0, -0.7, 0.5))
+    s = sc["spacing"]
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    dt, res = timed(lambda: reg.RegistrationICP(src, tgt, 3 * s, np.eye(4), reg.TransformationEstimationPointToPoint(), ctx=ctx), 5)
+    ips, _ = device_loop(sc["source"], sc["target"], None, 3 * s, reg.TransformationEstimationPointToPoint(), 200)
+    print(json.dumps({"config": 1, "what": "P2P 100k x 100k, r = 3 s, default criteria, whole call from host buffers",
+                      "call_ms": 1e3 * dt, "iterations": res.iterations_, "fitness": res.fitness_,
+                      "device_loop_iters_per_s": ips}), flush=True)
+
+if "2" in which:  # config 2: point-to-plane 1M, normals from EstimateNormals(Hybrid(4 s, 30))
+    sc = synthetic.make_pair(1_000_000, 1_000_000, cfg_id=2)
+    s = sc["spacing"]
+    tgt = geometry.PointCloud(sc["target"])
+    dtn, _ = timed(lambda: tgt.EstimateNormals(geometry.KDTreeSearchParamHybrid(4 * s, 30), ctx=ctx))
+    src = geometry.PointCloud(sc["source"])
+    dt, res = timed(lambda: reg.RegistrationICP(src, tgt, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx), 3)
+    ips, setup = device_loop(sc["source"], sc["target"], tgt.normals_, 2 * s, reg.TransformationEstimationPointToPlane(), 200)
+    print(json.dumps({"config": 2, "what": "P2Plane 1M x 1M, r = 2 s", "estimate_normals_ms": 1e3 * dtn, "call_ms_default_criteria": 1e3 * dt,
+                      "iterations": res.iterations_, "device_loop_iters_per_s": ips, "grid_build_ms": float(setup[0]),
+                      "source_sort_ms": float(setup[1])}), flush=True)
+
+if "3" in which:  # config 3 pipeline: 10M raw -> VoxelDownSample(2 s) both -> EstimateNormals -> P2Plane ICP r = 2 v
+    sc = synthetic.make_pair(10_000_000, 10_000_000, cfg_id=3)
+    s = sc["spacing"]
+    v = 2 * s
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    t0 = time.perf_counter()
+    sv = src.VoxelDownSample(v, ctx=ctx)
+    tv = tgt.VoxelDownSample(v, ctx=ctx)
+    t1 = time.perf_counter()
+    tv.EstimateNormals(geometry.KDTreeSearchParamHybrid(2 * v, 30), ctx=ctx)
+    t2 = time.perf_counter()
+    res = reg.RegistrationICP(sv, tv, 2 * v, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx)
+    t3 = time.perf_counter()
+    print(json.dumps({"config": 3, "what": "10M raw -> VoxelDownSample(2 s) x2 -> EstimateNormals(Hybrid(2 v, 30)) -> P2Plane ICP r = 2 v; "
+                                           "host buffers, PCIe included",
+                      "voxel_ms_both": 1e3 * (t1 - t0), "n_after": [len(sv.points_), len(tv.points_)], "normals_ms": 1e3 * (t2 - t1),
+                      "icp_ms": 1e3 * (t3 - t2), "iterations": res.iterations_, "fitness": res.fitness_, "total_ms": 1e3 * (t3 - t0)}),
+          flush=True)
+
+if "5" in which:  # config 5 in part: 64 pairs x 200k, P2Plane, criteria (0, 0, 30)
+    npairs, n = 64, 200_000
+    S, T_ = [], []
+    for k in range(npairs):
+        sc = synthetic.make_pair(n, n, cfg_id=1000 + k, L=2.83)
+        s = sc["spacing"]
+        nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+        S.append(geometry.PointCloud(sc["source"]))
+        T_.append(geometry.PointCloud(sc["target"], normals=nrm))
+    crit = reg.ICPConvergenceCriteria(0.0, 0.0, 30)
+    est = reg.TransformationEstimationPointToPlane()
+    out = {}
+    for w in (1, 4, 8):
+        dt, res = timed(lambda: reg.RegistrationICPBatch(S, T_, 2 * s, None, est, crit, n_workers=w, ctx=ctx))
+        out["pairs_per_s_workers_%d" % w] = npairs / dt
+    print(json.dumps({"config": 5, "what": "64 of the 4096 pairs x 200k points, P2Plane, r = 2 s, criteria (0,0,30); host buffers "
+                                           "(2 x 4.8 MB + normals per pair over PCIe), analytic normals", **out,
+                      "iterations": res[0].iterations_}), flush=True)

@@ -66,3 +66,48 @@ def test_surface_1m_matches_kdtree_oracle(ctx, oracle):
     from conftest import make_scene
     sc = make_scene(1_000_000, 1_000_000, cfg_id=2, L=6.32)
     _check(ctx, oracle, sc["source"], sc["target"], 2 * sc["spacing"])
+
+
+def test_headline_size_10m_properties(ctx, oracle):
+    """BASELINE headline size (10 M x 10 M, point-to-plane): the oracle is too slow for a full run, so the full-size run is
+    checked through size-independent properties -- (1) on a 100 k sample of source points the correspondences equal the
+    oracle's KD-tree search over the full 10 M target, bit for bit; (2) permuting the source permutes the result and leaves
+    fitness / rmse / transformation unchanged (the Hilbert processing order and the fixed-order reductions are internal);
+    (3) every reported match is inside the radius and the summary numbers follow from the correspondence array."""
+    from open3d_amd import geometry, synthetic
+    from open3d_amd.pipelines import registration as reg
+    n = 10_000_000
+    sc = synthetic.make_pair(n, n, cfg_id=3)
+    s = sc["spacing"]
+    r = 2 * s
+    src, tgt = sc["source"], sc["target"]
+    nrm = synthetic.surface_normals(tgt[:, 0], tgt[:, 1])
+    crit = reg.ICPConvergenceCriteria(0.0, 0.0, 3)
+    est = reg.TransformationEstimationPointToPlane()
+    target = geometry.PointCloud(tgt, normals=nrm)
+    got = reg.RegistrationICP(geometry.PointCloud(src), target, r, np.eye(4), est, crit, ctx=ctx)
+    assert got.iterations_ == 3 and got.fitness_ > 0.99
+
+    # (3) consistency of the summary with the correspondences
+    m = got.corr_ >= 0
+    T = got.transformation_
+    moved = src[m] @ T[:3, :3].T + T[:3, 3]
+    d2 = ((moved - tgt[got.corr_[m]]) ** 2).sum(1)
+    assert d2.max() < oracle.radius_threshold(r) * (1 + 1e-9)
+    assert got.fitness_ == m.sum() / n
+    assert abs(got.inlier_rmse_ - np.sqrt(d2.mean())) < 1e-9 * got.inlier_rmse_
+
+    # (1) sample against the KD-tree oracle over the full target, under the final transformation
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(n, 100_000, replace=False))
+    ev = reg.EvaluateRegistration(geometry.PointCloud(src), geometry.PointCloud(tgt), r, T, ctx=ctx)
+    assert np.array_equal(ev.corr_, got.corr_)          # the loop's last search == a fresh evaluation at its result
+    ref_corr = oracle.evaluate_registration(src[pick], tgt, r, T)[0]
+    assert np.array_equal(ev.corr_[pick], ref_corr)
+
+    # (2) permutation of the source
+    perm = rng.permutation(n)
+    got_p = reg.RegistrationICP(geometry.PointCloud(src[perm]), target, r, np.eye(4), est, crit, ctx=ctx)
+    assert np.array_equal(got_p.corr_, got.corr_[perm])
+    assert got_p.fitness_ == got.fitness_
+    assert np.abs(got_p.transformation_ - T).max() < 1e-12 and abs(got_p.inlier_rmse_ - got.inlier_rmse_) < 1e-15
