@@ -531,6 +531,27 @@ inline RegistrationResult RegistrationColoredICP(const o3d_types::PointCloud &so
   return result;
 }
 
+// ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159.  Returns the storage of Feature::data_ (33 x n,
+// column-major: 33 consecutive doubles per point); inside the reference tree, map it with
+// Eigen::Map<Eigen::MatrixXd>(v.data(), 33, n).
+inline std::vector<double> ComputeFPFHFeatureData(const o3d_types::PointCloud &input,
+                                                  const o3d_types::KDTreeSearchParam &param = o3d_types::KDTreeSearchParamKNN(),
+                                                  Context &c = Context::Default()) {
+  if (!input.HasNormals()) throw std::runtime_error("[Open3D ERROR] [ComputeFPFHFeature] Failed because input point cloud has no normal.");
+  int type = (int)param.GetSearchType(), knn = 0;
+  double radius = 0.0;
+  if (type == O3D_SEARCH_KNN) knn = static_cast<const o3d_types::KDTreeSearchParamKNN &>(param).knn_;
+  else if (type == O3D_SEARCH_RADIUS) radius = static_cast<const o3d_types::KDTreeSearchParamRadius &>(param).radius_;
+  else {
+    radius = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).radius_;
+    knn = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).max_nn_;
+  }
+  std::vector<double> data(33 * input.points_.size());
+  Check(c.get(), o3d_compute_fpfh_feature(c.get(), (const double *)input.points_.data(), (const double *)input.normals_.data(),
+                                          (int64_t)input.points_.size(), type, knn, radius, O3D_MEM_HOST, data.data()));
+  return data;
+}
+
 // GetInformationMatrixFromPointClouds, Registration.cpp:303-355
 inline o3d_types::Mat6 GetInformationMatrixFromPointClouds(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                                            double max_correspondence_distance,

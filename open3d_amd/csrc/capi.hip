@@ -34,6 +34,9 @@ int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int se
 int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int64_t n_cloud, const double *q_xyz, int64_t n_q,
                             int knn, double radius, int mem, double *out, int32_t *out_count);
 
+int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n, int search_type, int knn, double radius, int mem,
+                  double *out_feature);
+
 static thread_local std::string g_err_noctx;
 
 int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...) {
@@ -888,6 +891,14 @@ int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_nei
   O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_neighbor_query_impl(ctx, 1, xyz, n, xyz, n, nb_neighbors, 0.0, mem, out_mean, nullptr);
+}
+
+int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *normals, int64_t n, int search_type, int knn, double radius,
+                             int mem, double *out_feature) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_fpfh_impl(ctx, xyz, normals, n, search_type, knn, radius, mem, out_feature);
 }
 
 }  // extern "C"

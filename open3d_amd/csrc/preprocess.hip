@@ -579,6 +579,151 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
   }
 }
 
+// ---- FPFH, pipelines/registration/Feature.cpp:39-159 -------------------------------------------------------------------
+
+// The neighbour list of one query (KDTreeFlann::Search with a KNN or hybrid parameter): the l.cap nearest with d2 < l.thr,
+// ascending by (d2, index).  KNN (l.thr = inf) grows the searched cube shell by shell; hybrid needs the 3x3x3 block only
+// (cell size >= radius).
+__device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                                  const GridParams &gp, double qx, double qy, double qz, bool knn_mode) {
+  const int cx = min(max(o3d_cell_coord(qx, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+  const int cy = min(max(o3d_cell_coord(qy, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+  const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+  const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
+  l.count = 0;
+  for (int R = 1;; R++) {
+    for (int dz = -R; dz <= R; dz++) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= gp.nz) continue;
+      for (int dy = -R; dy <= R; dy++) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= gp.ny) continue;
+        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+        const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
+        const int nseg = face ? 1 : 2;
+        for (int sgi = 0; sgi < nseg; sgi++) {
+          int xa, xb;
+          if (face) { xa = cx - R; xb = cx + R; }
+          else if (sgi == 0) { xa = xb = cx - R; }
+          else { xa = xb = cx + R; }
+          xa = max(xa, -1); xb = min(xb, gp.nx);
+          if (xa > xb) continue;
+          const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+          for (uint32_t j = s; j < e; j++) {
+            const double4 t = pts[j];
+            const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
+            double d2 = ddx * ddx;
+            d2 = d2 + ddy * ddy;
+            d2 = d2 + ddz * ddz;
+            if (d2 <= klist_worst(l)) klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+          }
+        }
+      }
+    }
+    if (!knn_mode) break;
+    if (R >= max_dim) break;
+    if (l.count == l.cap) {
+      const double reach = (double)R * gp.h * (1.0 - 1e-6);
+      if (klist_worst(l) <= reach * reach) break;
+    }
+  }
+}
+
+// ComputePairFeatures, Feature.cpp:39-69
+__device__ void pair_features(const double *p1, const double *n1, const double *p2, const double *n2, double *f) {
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  f[0] = f[1] = f[2] = f[3] = 0.0;
+  const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  if (len == 0.0) return;
+  double a[3] = {n1[0], n1[1], n1[2]}, b[3] = {n2[0], n2[1], n2[2]};
+  const double angle1 = ((a[0] * d[0] + a[1] * d[1]) + a[2] * d[2]) / len;
+  const double angle2 = ((b[0] * d[0] + b[1] * d[1]) + b[2] * d[2]) / len;
+  double f2;
+  if (acos(fabs(angle1)) > acos(fabs(angle2))) {
+    for (int k = 0; k < 3; k++) { a[k] = n2[k]; b[k] = n1[k]; d[k] *= -1.0; }
+    f2 = -angle2;
+  } else {
+    f2 = angle1;
+  }
+  double v[3];
+  cross3(d, a, v);
+  const double vn = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  if (vn == 0.0) return;
+  for (int k = 0; k < 3; k++) v[k] /= vn;
+  double w[3];
+  cross3(a, v, w);
+  f[3] = len;
+  f[2] = f2;
+  f[1] = (v[0] * b[0] + v[1] * b[1]) + v[2] * b[2];
+  f[0] = atan2((w[0] * b[0] + w[1] * b[1]) + w[2] * b[2], (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]);
+}
+
+__device__ __forceinline__ int fpfh_bin(double v) {
+  int h = (int)floor(v);
+  return h < 0 ? 0 : (h >= 11 ? 10 : h);
+}
+
+// PASS 0: ComputeSPFHFeature (Feature.cpp:71-111) -> spfh[33 * i + j].  PASS 1: the weighting of ComputeFPFHFeature
+// (:127-157) -> out[33 * i + j], reading spfh.  Both search the neighbours again, like the reference.  Features are 33
+// doubles per point (Feature::data_ is a column-major 33 x n Eigen matrix), in the caller's point order.
+template <int PASS>
+__global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ pts, int64_t n_grid, const uint32_t *__restrict__ cell_start,
+                                                     GridParams gp, int knn, double thr, int knn_mode, const double *__restrict__ normals,
+                                                     const double *__restrict__ spfh, double *__restrict__ out) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  KList l;
+  l.d2 = reinterpret_cast<double *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.idx = l.pos + kNrmBlock * (size_t)knn;
+  l.cap = knn;
+  l.thr = knn_mode ? INFINITY : thr;
+  for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
+    const double4 q = pts[p];
+    const size_t qi = (size_t)__double_as_longlong(q.w);
+    collect_neighbors(l, pts, cell_start, gp, q.x, q.y, q.z, knn_mode != 0);
+    double *o = out + 33 * qi;
+    if (PASS == 0) {
+      // the row was zeroed by the host; one lane owns it
+      if (l.count > 1) {
+        const double hist_incr = 100.0 / (double)(l.count - 1);
+        const double p1[3] = {q.x, q.y, q.z};
+        const double n1[3] = {normals[3 * qi], normals[3 * qi + 1], normals[3 * qi + 2]};
+        for (int k = 1; k < l.count; k++) {
+          const double4 t = pts[l.pos[k * kNrmBlock]];
+          const size_t ti = l.idx[k * kNrmBlock];
+          const double p2[3] = {t.x, t.y, t.z};
+          const double n2[3] = {normals[3 * ti], normals[3 * ti + 1], normals[3 * ti + 2]};
+          double f[4];
+          pair_features(p1, n1, p2, n2, f);
+          o[fpfh_bin(11 * (f[0] + M_PI) / (2.0 * M_PI))] += hist_incr;
+          o[fpfh_bin(11 * (f[1] + 1.0) * 0.5) + 11] += hist_incr;
+          o[fpfh_bin(11 * (f[2] + 1.0) * 0.5) + 22] += hist_incr;
+        }
+      }
+    } else if (l.count > 1) {
+      double sum[3] = {0.0, 0.0, 0.0};
+      for (int k = 1; k < l.count; k++) {
+        const double dist = l.d2[k * kNrmBlock];
+        if (dist == 0.0) continue;
+        const double *sp = spfh + 33 * (size_t)l.idx[k * kNrmBlock];
+        for (int j = 0; j < 33; j++) {
+          const double val = sp[j] / dist;
+          sum[j / 11] += val;
+          o[j] += val;
+        }
+      }
+      for (int j = 0; j < 3; j++)
+        if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+      const double *self = spfh + 33 * qi;
+      for (int j = 0; j < 33; j++) {
+        o[j] *= sum[j / 11];
+        o[j] += self[j];
+      }
+    }
+  }
+}
+
 // Non-finite points are not in the grid: FLANN finds no finite-distance neighbour for them -> fewer than 3 -> (0,0,1).
 __global__ __launch_bounds__(O3D_BLOCK) void k_normals_nonfinite(const double *__restrict__ xyz, int64_t n, double *__restrict__ normals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -897,6 +1042,68 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST)
       O3D_HIP(ctx, hipMemcpyAsync(mode == 2 ? (void *)out_count : (void *)out, so, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return O3D_OK;
+  };
+  const int st = run();
+  cleanup();
+  return st;
+}
+
+// ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159.  out_feature: 33 doubles per point (`mem` space).
+int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n, int search_type, int knn, double radius, int mem,
+                  double *out_feature) {
+  if (n < 0 || (n > 0 && (!xyz || !out_feature))) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "ComputeFPFHFeature: null buffer");
+  if (!nrm && n > 0)
+    return o3d_fail(ctx, O3D_ERR_NEED_NORMALS, "[Open3D ERROR] [ComputeFPFHFeature] Failed because input point cloud has no normal.");
+  if (search_type != O3D_SEARCH_KNN && search_type != O3D_SEARCH_HYBRID)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: only KNN and hybrid search parameters are on the device path");
+  if (knn > kMaxKnn) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: knn/max_nn > %d is not on the device path", kMaxKnn);
+  if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: more than 2^31-1 points");
+  if (n == 0) return O3D_OK;
+  ctx->icp_ready = 0;
+  const size_t pbytes = sizeof(double) * 3 * (size_t)n, fbytes = sizeof(double) * 33 * (size_t)n;
+  const double *d_xyz = xyz, *d_nrm = nrm;
+  double *d_out = out_feature;
+  void *sx = nullptr, *sn = nullptr, *so = nullptr, *sp = nullptr;
+  auto cleanup = [&]() {
+    for (void *b : {sx, sn, so, sp})
+      if (b) (void)hipFree(b);
+  };
+  auto run = [&]() -> int {
+    if (mem == O3D_MEM_HOST) {
+      O3D_HIP(ctx, hipMalloc(&sx, pbytes));
+      O3D_HIP(ctx, hipMalloc(&sn, pbytes));
+      O3D_HIP(ctx, hipMalloc(&so, fbytes));
+      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, pbytes, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, hipMemcpyAsync(sn, nrm, pbytes, hipMemcpyHostToDevice, ctx->stream));
+      d_xyz = (const double *)sx; d_nrm = (const double *)sn; d_out = (double *)so;
+    }
+    O3D_HIP(ctx, hipMalloc(&sp, fbytes));
+    O3D_HIP(ctx, hipMemsetAsync(sp, 0, fbytes, ctx->stream));
+    O3D_HIP(ctx, hipMemsetAsync(d_out, 0, fbytes, ctx->stream));
+    const bool knn_mode = search_type == O3D_SEARCH_KNN;
+    if (knn < 1 || (!knn_mode && !(radius > 0.0))) {  // no point has a neighbour besides (at most) itself: all zero
+      if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(out_feature, d_out, fbytes, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return O3D_OK;
+    }
+    double h = radius;
+    if (knn_mode) O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h));
+    else O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius));
+    const int64_t ng = ctx->n_tgt_grid;
+    if (ng > 0) {
+      const double thr = (double)(float)(radius * radius);
+      const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)knn;
+      int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
+      g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+      hipLaunchKernelGGL(k_fpfh<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
+                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)nullptr, (double *)sp);
+      hipLaunchKernelGGL(k_fpfh<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
+                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)sp, d_out);
+      O3D_HIP(ctx, hipGetLastError());
+    }
+    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(out_feature, d_out, fbytes, hipMemcpyDeviceToHost, ctx->stream));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return O3D_OK;
   };

@@ -243,6 +243,34 @@ def RegistrationICPBatch(sources, targets, max_correspondence_distance, inits=No
     return out
 
 
+class Feature:
+    """pipelines/registration/Feature.h: data_ is dim x n (one column per point)."""
+
+    def __init__(self, data=None):
+        self.data_ = np.zeros((33, 0)) if data is None else data
+
+    def Dimension(self):
+        return self.data_.shape[0]
+
+    def Num(self):
+        return self.data_.shape[1]
+
+
+def ComputeFPFHFeature(input, search_param=None, ctx=None):
+    """ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159."""
+    from ..geometry import KDTreeSearchParamKNN
+    ctx = ctx or _lib.default_context()
+    sp = search_param or KDTreeSearchParamKNN()
+    if not input.HasNormals():
+        raise _lib.O3DError(2, "[Open3D ERROR] [ComputeFPFHFeature] Failed because input point cloud has no normal.")
+    pts = np.ascontiguousarray(input.points_, dtype=np.float64)
+    nrm = np.ascontiguousarray(input.normals_, dtype=np.float64)
+    out = np.zeros((max(len(pts), 1), 33))
+    ctx.check(ctx._lib.o3d_compute_fpfh_feature(ctx.handle, _lib.ptr(pts), _lib.ptr(nrm), len(pts), sp.search_type, sp.knn_, sp.radius_,
+                                                _lib.MEM_HOST, _lib.ptr(out)))
+    return Feature(out[: len(pts)].T)  # a 33 x n view of the column-major storage
+
+
 def EvaluateHypotheses(source, target, max_correspondence_distance, transformations, want_corr=True, ctx=None):
     """The validation step of RegistrationRANSACBasedOnFeatureMatching (Registration.cpp:269-275) for a list of candidate
     transformations.  Returns (fitness[k], inlier_rmse[k], best RegistrationResult or None): `best` is the hypothesis

@@ -264,6 +264,15 @@ def registration_colored_icp(src, src_col, tgt, tgt_nrm, tgt_col, max_dist, init
     return r
 
 
+def fpfh(pts, normals, search_type=0, knn=30, radius=0.0, want_spfh=False):
+    """ComputeFPFHFeature, Feature.cpp:113-159 -> features [n, 33] (and the SPFH)."""
+    pts, normals = _pts(pts), _pts(normals)
+    f = np.zeros((len(pts), 33))
+    sp = np.zeros((len(pts), 33))
+    lib().orc_fpfh(_d(pts), _d(normals), C.c_int64(len(pts)), int(search_type), int(knn), C.c_double(radius), _d(f), _d(sp))
+    return (f, sp) if want_spfh else f
+
+
 def neighbor_query(mode, cloud, queries, knn=1, radius=0.0):
     """PointCloud.cpp:112-132 (mode 0, knn 1), :521-544 (mode 0, knn 2 on itself), :438-449 (mode 1), :406-411 (mode 2)."""
     cloud, queries = _pts(cloud), _pts(queries)

@@ -1049,6 +1049,109 @@ ORC_EXPORT void orc_neighbor_query(int mode, const double *cloud, int64_t nc, co
   orc_kdtree_free(kd);
 }
 
+/* ------------------------------------------------------------------------- */
+/* FPFH, pipelines/registration/Feature.cpp:39-159.  search_type 0 = KNN,        */
+/* 2 = hybrid.  feature: 33 doubles per point (Feature::data_, column-major).    */
+/* ------------------------------------------------------------------------- */
+static void pair_features(const double *p1, const double *n1, const double *p2, const double *n2, double *f) { /* :39-69 */
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  f[0] = f[1] = f[2] = f[3] = 0.0;
+  const double len = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  if (len == 0.0) return;
+  double a[3] = {n1[0], n1[1], n1[2]}, b[3] = {n2[0], n2[1], n2[2]};
+  const double angle1 = ((a[0] * d[0] + a[1] * d[1]) + a[2] * d[2]) / len;
+  const double angle2 = ((b[0] * d[0] + b[1] * d[1]) + b[2] * d[2]) / len;
+  double f2;
+  if (acos(fabs(angle1)) > acos(fabs(angle2))) {
+    for (int k = 0; k < 3; k++) { a[k] = n2[k]; b[k] = n1[k]; d[k] *= -1.0; }
+    f2 = -angle2;
+  } else {
+    f2 = angle1;
+  }
+  double v[3], w[3];
+  cross3(d, a, v);
+  const double vn = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  if (vn == 0.0) return;
+  for (int k = 0; k < 3; k++) v[k] /= vn;
+  cross3(a, v, w);
+  f[3] = len;
+  f[2] = f2;
+  f[1] = (v[0] * b[0] + v[1] * b[1]) + v[2] * b[2];
+  f[0] = atan2((w[0] * b[0] + w[1] * b[1]) + w[2] * b[2], (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]);
+}
+
+static int fpfh_bin(double v) {
+  int h = (int)floor(v);
+  return h < 0 ? 0 : (h >= 11 ? 10 : h);
+}
+
+static int fpfh_search(const orc_kdtree *kd, const double *q, int search_type, int knn, double radius, int *idx, double *d2) {
+  return search_type == 0 ? orc_kdtree_search_knn(kd, q, knn, idx, d2) : orc_kdtree_search_hybrid(kd, q, radius, knn, idx, d2);
+}
+
+ORC_EXPORT void orc_fpfh(const double *pts, const double *nrm, int64_t n, int search_type, int knn, double radius, double *feature,
+                         double *spfh_out /* nullable */) {
+  const double kPi = 3.14159265358979323846;
+  orc_kdtree *kd = orc_kdtree_build(pts, n);
+  double *spfh = (double *)calloc((size_t)(n > 0 ? n : 1) * 33, sizeof(double));
+  memset(feature, 0, sizeof(double) * 33 * (size_t)n);
+  const int cap = knn > 0 ? knn : 1;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    int *idx = (int *)malloc(sizeof(int) * (size_t)cap);
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)cap);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) { /* ComputeSPFHFeature :78-109 */
+      const int k = knn > 0 ? fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2) : 0;
+      if (k > 1) {
+        const double hist_incr = 100.0 / (double)(k - 1);
+        double *o = spfh + 33 * i;
+        for (int j = 1; j < k; j++) {
+          double f[4];
+          pair_features(pts + 3 * i, nrm + 3 * i, pts + 3 * (size_t)idx[j], nrm + 3 * (size_t)idx[j], f);
+          o[fpfh_bin(11 * (f[0] + kPi) / (2.0 * kPi))] += hist_incr;
+          o[fpfh_bin(11 * (f[1] + 1.0) * 0.5) + 11] += hist_incr;
+          o[fpfh_bin(11 * (f[2] + 1.0) * 0.5) + 22] += hist_incr;
+        }
+      }
+    }
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) { /* :127-157 */
+      const int k = knn > 0 ? fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2) : 0;
+      if (k > 1) {
+        double sum[3] = {0.0, 0.0, 0.0};
+        double *o = feature + 33 * i;
+        for (int j = 1; j < k; j++) {
+          const double dist = d2[j];
+          if (dist == 0.0) continue;
+          for (int b = 0; b < 33; b++) {
+            const double val = spfh[33 * (size_t)idx[j] + b] / dist;
+            sum[b / 11] += val;
+            o[b] += val;
+          }
+        }
+        for (int b = 0; b < 3; b++)
+          if (sum[b] != 0.0) sum[b] = 100.0 / sum[b];
+        for (int b = 0; b < 33; b++) {
+          o[b] *= sum[b / 11];
+          o[b] += spfh[33 * i + b];
+        }
+      }
+    }
+    free(idx);
+    free(d2);
+  }
+  if (spfh_out) memcpy(spfh_out, spfh, sizeof(double) * 33 * (size_t)n);
+  free(spfh);
+  orc_kdtree_free(kd);
+}
+
 /* EvaluateRegistration, Registration.cpp:118-127 */
 ORC_EXPORT int orc_evaluate_registration(const double *src, int64_t ns, const double *tgt, int64_t nt, double max_dist,
                                          const double *T, int use_brute, int32_t *corr_out, int64_t *n_corr, double *fitness,

@@ -201,3 +201,45 @@ def test_outlier_removal_matches_oracle(ctx, oracle):
     with pytest.raises(_lib.O3DError):
         pc.RemoveStatisticalOutliers(0, 1.0, ctx=ctx)
     assert len(geometry.PointCloud().RemoveStatisticalOutliers(5, 1.0, ctx=ctx)[1]) == 0
+
+
+@pytest.mark.parametrize("mode", ["knn", "hybrid"])
+def test_fpfh_matches_oracle(ctx, oracle, mode):
+    """ComputeFPFHFeature (Feature.cpp:113-159).  Same neighbour lists and summation order as the oracle; histogram bins
+    come from acos / atan2 / sqrt of the device's libm, which may differ from the host's in the last ulp, so a bin can flip
+    only when a value sits on a bin edge to within an ulp: the features must agree to 1e-9 on all but a handful of points."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(100, 20000, cfg_id=33)
+    s = sc["spacing"]
+    pts = sc["target"]
+    nrm = oracle.estimate_normals(pts, oracle.HYBRID, 30, 4 * s)
+    pc = geometry.PointCloud(pts, normals=nrm)
+    if mode == "knn":
+        sp, args = geometry.KDTreeSearchParamKNN(30), (oracle.KNN, 30, 0.0)
+    else:
+        sp, args = geometry.KDTreeSearchParamHybrid(5 * s, 40), (oracle.HYBRID, 40, 5 * s)
+    got = reg.ComputeFPFHFeature(pc, sp, ctx=ctx)
+    ref = oracle.fpfh(pts, nrm, *args)
+    assert got.Dimension() == 33 and got.Num() == len(pts)
+    g = got.data_.T
+    # every histogram of a point with neighbours sums to 100 (three of them) up to rounding... before the SPFH is added: 200
+    tot = g.reshape(len(pts), 3, 11).sum(2)
+    assert np.allclose(tot[tot[:, 0] > 0], 200.0, rtol=1e-9)
+    bad = np.abs(g - ref).max(1) > 1e-9 * 100.0
+    assert bad.sum() <= max(3, len(pts) // 2000), "too many points differ: %d" % bad.sum()
+
+
+def test_fpfh_edge_cases(ctx):
+    from open3d_amd import geometry, _lib
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(10, 500, cfg_id=34)
+    with pytest.raises(_lib.O3DError):
+        reg.ComputeFPFHFeature(geometry.PointCloud(sc["target"]), ctx=ctx)        # no normals: Feature.cpp:117-121
+    nrm = np.tile([0.0, 0.0, 1.0], (500, 1))
+    pc = geometry.PointCloud(sc["target"], normals=nrm)
+    assert not reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamHybrid(1e-9, 30), ctx=ctx).data_.any()   # nobody has a neighbour
+    with pytest.raises(_lib.O3DError):
+        reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamRadius(0.1), ctx=ctx)   # radius search: not on the device path
+    one = geometry.PointCloud(sc["target"][:1], normals=nrm[:1])
+    assert reg.ComputeFPFHFeature(one, ctx=ctx).data_.shape == (33, 1)

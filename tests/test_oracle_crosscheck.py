@@ -319,3 +319,58 @@ def test_colored_icp_pieces_vs_numpy(oracle):
     x = np.linalg.solve(J.T @ J, -(J.T @ r))
     assert np.allclose(T, oracle.vec6_to_mat4(x), rtol=1e-8, atol=1e-12)
     assert np.isclose(oracle.colored_rmse(src, scol, tgt, nrm, tcol, grad, corr, lam), (r * r).sum(), rtol=1e-10)
+
+
+def test_fpfh_vs_numpy(oracle):
+    """Feature.cpp:39-159 restated with numpy for a few points (brute-force neighbour lists)."""
+    sc = make_scene(10, 1500, cfg_id=404)
+    pts = sc["target"]
+    nrm = oracle.estimate_normals(pts, oracle.KNN, 20)
+    k = 12
+    feat, spfh = oracle.fpfh(pts, nrm, oracle.KNN, k, 0.0, want_spfh=True)
+
+    def knn(i):
+        d2 = ((pts - pts[i]) ** 2).sum(1)
+        order = np.lexsort((np.arange(len(pts)), d2))[:k]
+        return order, d2[order]
+
+    def pair(p1, n1, p2, n2):
+        d = p2 - p1
+        L = np.linalg.norm(d)
+        if L == 0:
+            return np.zeros(4)
+        a1, a2 = n1 @ d / L, n2 @ d / L
+        if np.arccos(abs(a1)) > np.arccos(abs(a2)):
+            n1, n2, d, f2 = n2, n1, -d, -a2
+        else:
+            f2 = a1
+        v = np.cross(d, n1)
+        if np.linalg.norm(v) == 0:
+            return np.zeros(4)
+        v = v / np.linalg.norm(v)
+        w = np.cross(n1, v)
+        return np.array([np.arctan2(w @ n2, n1 @ n2), v @ n2, f2, L])
+
+    def spfh_of(i):
+        idx, _ = knn(i)
+        h = np.zeros(33)
+        for j in idx[1:]:
+            f = pair(pts[i], nrm[i], pts[j], nrm[j])
+            b = [int(np.clip(np.floor(11 * (f[0] + np.pi) / (2 * np.pi)), 0, 10)),
+                 int(np.clip(np.floor(11 * (f[1] + 1) * 0.5), 0, 10)) + 11,
+                 int(np.clip(np.floor(11 * (f[2] + 1) * 0.5), 0, 10)) + 22]
+            for bb in b:
+                h[bb] += 100.0 / (len(idx) - 1)
+        return h
+
+    for i in (0, 7, 333, 1499):
+        assert np.allclose(spfh[i], spfh_of(i), atol=1e-9)
+        idx, d2 = knn(i)
+        acc = np.zeros(33)
+        for j, d in zip(idx[1:], d2[1:]):
+            if d > 0:
+                acc += spfh[j] / d
+        s3 = acc.reshape(3, 11).sum(1)
+        scale = np.where(s3 != 0, 100.0 / np.where(s3 != 0, s3, 1), 0.0)
+        want = (acc.reshape(3, 11) * scale[:, None]).reshape(33) + spfh[i]
+        assert np.allclose(feat[i], want, rtol=1e-10, atol=1e-9)
