@@ -18,6 +18,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
 int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset);
+int o3d_take_bound_violations(o3d_ctx *ctx, unsigned int *out);
 int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
 int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
                      const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad);
@@ -178,7 +179,7 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   ctx->stream = ctx->own_stream;
   if ((e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   if ((e = hipMalloc((void **)&ctx->state, sizeof(IcpState))) != hipSuccess) return bail(e, "hipMalloc state");
-  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * (O3D_MAX_GRID + O3D_FIX_GRID))) != hipSuccess) return bail(e, "hipMalloc partials");
+  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
   if ((e = hipMalloc((void **)&ctx->sums, sizeof(double) * O3D_NSUMS)) != hipSuccess) return bail(e, "hipMalloc sums");
   *out_ctx = ctx;
   return O3D_OK;
@@ -192,7 +193,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->pos_sorted, ctx->pend_mask, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
+                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -224,6 +225,16 @@ int o3d_ctx_use_own_stream(o3d_ctx *ctx) {
   DeviceGuard guard(ctx->device);
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = ctx->own_stream;
+  return O3D_OK;
+}
+
+// The fp32 prefilter's error bound is checked on every winner (k_icp_search_coop); a violation makes the result suspect.
+static int check_bound_violations(o3d_ctx *ctx) {
+  unsigned int v = 0;
+  O3D_TRY(o3d_take_bound_violations(ctx, &v));
+  if (v)
+    return o3d_fail(ctx, O3D_ERR_STATE, "internal: %u fp32 prefilter winner(s) failed their fp64 confirmation; the result is not "
+                    "trustworthy (o3d_debug_set(ctx, 1, 0) selects the all-fp64 path)", v);
   return O3D_OK;
 }
 
@@ -484,6 +495,7 @@ int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, i
   IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
   O3D_HIP(ctx, hipMemcpyAsync(hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  O3D_TRY(check_bound_violations(ctx));
   if (out_T) memcpy(out_T, hs->T, sizeof(double) * 16);
   if (out_n_corr) *out_n_corr = (int64_t)hs->n_corr;
   if (out_fitness) *out_fitness = hs->fitness;
@@ -692,6 +704,7 @@ int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr,
   double *hq = reinterpret_cast<double *>(ctx->pinned);
   O3D_HIP(ctx, hipMemcpyAsync(hq, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  O3D_TRY(check_bound_violations(ctx));
   const double nc = hq[O3D_SUM_NC];
   if (out_n_corr) *out_n_corr = (int64_t)nc;
   if (out_fitness) *out_fitness = nc > 0.0 ? nc / (double)ctx->n_src_global : 0.0;  // Registration.cpp:82-89

@@ -351,8 +351,7 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     if (ctx->corr_sorted) (void)hipFree(ctx->corr_sorted);
     if (ctx->corr_out) (void)hipFree(ctx->corr_out);
     if (ctx->pos_sorted) (void)hipFree(ctx->pos_sorted);
-    if (ctx->pend_mask) (void)hipFree(ctx->pend_mask);
-    ctx->pos_sorted = nullptr; ctx->pend_mask = nullptr;
+    ctx->pos_sorted = nullptr;
     ctx->src_sorted = nullptr; ctx->src_perm = nullptr; ctx->corr_sorted = nullptr; ctx->corr_out = nullptr;
     ctx->cap_src = 0;
     O3D_HIP(ctx, hipMalloc((void **)&ctx->src_sorted, sizeof(double) * 3 * nn));
@@ -360,7 +359,6 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_sorted, sizeof(int32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_out, sizeof(int32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->pos_sorted, sizeof(uint32_t) * nn));
-    O3D_HIP(ctx, hipMalloc((void **)&ctx->pend_mask, sizeof(unsigned long long) * (nn / 64 + 2)));
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;

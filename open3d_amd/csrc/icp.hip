@@ -262,6 +262,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
 // Optional counters of the cooperative search (tests and tuning): [0] wave trips, [1] dense item trips, [2] runs
 // listed, [3] lanes left to the exact fixup, [4] items (four candidates each), [5] valid lanes.
 __device__ unsigned long long g_tile_stats[8];
+// number of fp32 winners whose fp64 confirmation failed (must stay 0: see k_icp_search_coop)
+__device__ unsigned int g_bound_violations;
 
 struct PassArgs {
   int stats;
@@ -275,7 +277,6 @@ struct PassArgs {
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, -1 none, -2 left to k_icp_fixup, -3 unconfirmed candidate at pos
   uint32_t *pos;   // per processing position: position of the match in tgt_sorted
-  unsigned long long *pend;  // one bit per processing position: left to k_icp_fixup (word w covers positions 64w..64w+63)
   double *partials;
   double thr;
   // coloured ICP only (ColoredICP.cpp:125-177)
@@ -468,7 +469,8 @@ __device__ __forceinline__ void mfma_reduce_store(const v4f64 &S, double (*red)[
   }
 }
 
-// k_icp_accumulate with the sums on the matrix cores (same reads, same confirmation of the fp32 candidates).
+// Accumulation pass of the alternative path (after the per-lane fp64 search k_icp_search): streams the source with its
+// correspondences, gathers the matched target point (and normal) by position, sums on the matrix cores.
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
   if (a.st->done) return;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
     const int64_t i = base + threadIdx.x;
     int32_t c = O3D_CORR_NONE;
     if (i < end) c = a.corr[i];
-    bool use = c >= 0 || c == O3D_CORR_CANDIDATE;
+    const bool use = c >= 0;
     double x = 0.0, y = 0.0, z = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0, d2 = 0.0, is = 0.0;
     double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
     if (use) {
@@ -504,15 +506,6 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
       d2 = ddx * ddx;
       d2 = d2 + ddy * ddy;
       d2 = d2 + ddz * ddz;
-      if (c == O3D_CORR_CANDIDATE) {
-        if (d2 < a.thr) {
-          a.corr[i] = (int32_t)__double_as_longlong(p.w);
-        } else {
-          a.corr[i] = O3D_CORR_PENDING;  // cannot happen within the fp32 error bound; stay exact regardless
-          atomicOr(&a.pend[i >> 6], 1ull << (i & 63));
-          use = false;
-        }
-      }
     }
     push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
   }
@@ -653,6 +646,45 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, int lane, int first
   return trips;
 }
 
+// Exact fp64 search of one query's 3x3x3 block, for the few queries the fp32 prefilter cannot decide (near ties, winner
+// within the error bound of the threshold): argmin over (d2, original index) among d2 < thr, with the reference's
+// arithmetic.  rowp points at the table entry of the cell left of the query's; the grid's margin makes all nine rows
+// valid.  Rare (about 1e-4 of the queries on the headline scene), but a lane scanning ~40 candidates alone would stall its
+// wavefront for as many memory latencies, so the WHOLE wavefront serves one undecided query at a time: seven lanes per
+// row of the block, lexicographic wave reduction at the end.  Every lane must call it with the same (wave-uniform) query.
+__device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tgt, const uint32_t *rowp, int row_y, int row_z,
+                                                  double x, double y, double z, double thr, int lane, uint32_t &best_pos) {
+  const int r = lane / 7, k = lane % 7;
+  uint32_t s = 0, e = 0;
+  if (r < 9) {
+    const uint32_t *rp = rowp + ((r % 3 - 1) * row_y + (r / 3 - 1) * row_z);
+    s = rp[0]; e = rp[3];
+  }
+  int found = 0;
+  double bd = 0.0;
+  long long bi = 0;
+  uint32_t bp = 0;
+  for (uint32_t j = s + (uint32_t)k; j < e; j += 7) {
+    const double4 p = tgt[j];
+    const double dx = x - p.x, dy = y - p.y, dz = z - p.z;
+    double d2 = dx * dx;
+    d2 = d2 + dy * dy;
+    d2 = d2 + dz * dz;
+    const long long id = __double_as_longlong(p.w);
+    if (d2 < thr && (!found || d2 < bd || (d2 == bd && id < bi))) { found = 1; bd = d2; bi = id; bp = j; }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int of = __shfl_xor(found, d, O3D_WAVE);
+    const double od = __shfl_xor(bd, d, O3D_WAVE);
+    const long long oi = __shfl_xor(bi, d, O3D_WAVE);
+    const uint32_t op = (uint32_t)__shfl_xor((int)bp, d, O3D_WAVE);
+    if (of && (!found || od < bd || (od == bd && oi < bi))) { found = 1; bd = od; bi = oi; bp = op; }
+  }
+  best_pos = bp;
+  return found != 0;
+}
+
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
 template <int EST>
@@ -660,7 +692,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   if (a.st->done) return;
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
   static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
-  const int tid = threadIdx.x, lane = tid & 63, wave0 = tid & ~63;
+  const int tid = threadIdx.x, lane = tid & 63;
   CoopWave &wl = wls[tid >> 6];
   const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
@@ -682,7 +714,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
 
   // The fp32 winner is confirmed in fp64 with the arithmetic of the exact search (it then IS the exact result: every
   // other candidate is farther by more than the fp32 error bound), and its terms of the next estimate go to the matrix
-  // cores.  What is not decisive in fp32 is left to k_icp_fixup.  The gathers of the matched target point and normal
+  // cores.  What is not decisive in fp32 is searched again in fp64 on the spot (exact_block_search).  The gathers of the
+  // matched target point and normal
   // are issued at the end of a trip and consumed in the next one, behind that trip's own source loads, so that their
   // latency is not exposed.
   bool use_p = false;  // carried from the previous trip
@@ -691,19 +724,21 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0, is_p = 0.0;
   auto consume = [&]() {
     double d2 = 0.0;
+    const bool had_p = use_p;  // the lane brought a candidate: its correspondence entry is written here
     if (use_p) {
       const double ddx = xs - p_p.x, ddy = ys - p_p.y, ddz = zs - p_p.z;
       d2 = ddx * ddx;
       d2 = d2 + ddy * ddy;
       d2 = d2 + ddz * ddz;
-      if (d2 < a.thr) {
-        a.corr[i_p] = (int32_t)__double_as_longlong(p_p.w);
-      } else {  // cannot happen within the fp32 error bound; stay exact regardless
-        a.corr[i_p] = O3D_CORR_PENDING;
-        atomicOr(&a.pend[i_p >> 6], 1ull << (i_p & 63));
-        use_p = false;
-      }
     }
+    // A confirmation that fails would mean that the fp32 error bound does not hold (winners near the threshold were
+    // resolved exactly before they got here).  It is counted; o3d_icp_finish / o3d_icp_fetch then fail loudly instead of
+    // returning a result that might not be exact.
+    if (use_p && !(d2 < a.thr)) {
+      atomicAdd(&g_bound_violations, 1u);
+      use_p = false;
+    }
+    if (had_p) a.corr[i_p] = use_p ? (int32_t)__double_as_longlong(p_p.w) : O3D_CORR_NONE;
     // begins and ends with a wavefront LDS sync
     push_sums<EST>(wl.vb, lane, S, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0, tc_p, is_p, a.slg, a.slp);
   };
@@ -799,6 +834,17 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
       else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
     }
+    const unsigned long long undecided = __ballot(verdict == O3D_CORR_PENDING);
+    for (unsigned long long m = undecided; m; m &= m - 1) {  // wave-uniform, rare: one undecided query at a time
+      const int srcl = __ffsll((long long)m) - 1;
+      const double qx64 = __shfl(x, srcl, O3D_WAVE), qy64 = __shfl(y, srcl, O3D_WAVE), qz64 = __shfl(z, srcl, O3D_WAVE);
+      const unsigned long long rpb = (unsigned long long)(uintptr_t)rowp;
+      const unsigned long long rq = ((unsigned long long)(uint32_t)__shfl((int)(rpb >> 32), srcl, O3D_WAVE) << 32) |
+                                    (uint32_t)__shfl((int)(uint32_t)rpb, srcl, O3D_WAVE);
+      uint32_t ep = 0;
+      const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
+      if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; }
+    }
     // issue the gathers for this trip's candidates; they are consumed in the next trip (or after the loop)
     use_p = verdict == O3D_CORR_CANDIDATE;
     i_p = i;
@@ -811,7 +857,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[bpos]; is_p = a.sint[i]; }
     }
     if (a.stats) {
-      const unsigned long long np = __popcll(__ballot(verdict == O3D_CORR_PENDING)), nv = __popcll(__ballot(valid));
+      const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid));
       unsigned long long rsum = (unsigned long long)nruns, isum = tot + ((s2 - s1 + 3u) >> 2);
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
@@ -831,86 +877,11 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       if (!use_p) a.corr[i] = verdict;  // a candidate's entry is written when it is confirmed
       a.pos[i] = bpos;
     }
-    const unsigned long long pm = __ballot(verdict == O3D_CORR_PENDING);
-    if (lane == 0 && base + wave0 < end) a.pend[(base + wave0) >> 6] = pm;
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
   if (beg < end) consume();
   __syncthreads();
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, chunk);
-}
-
-// Exact per-lane fp64 search for the points the fp32 prefilter search left undecided (corr == -2).  Each workgroup walks a
-// contiguous slice of the source in 4096-point tiles, compacts the pending indices of a tile into LDS in index order
-// (block prefix scan: deterministic), and processes the compact list densely.  Its sums go to partial rows of their
-// own behind the tile pass's rows.
-constexpr int kFixTile = 4096;   // points per scan step: 64 mask words, one per lane of the first wave
-constexpr int kFixList = 8192;   // pending indices gathered in LDS before they are searched
-template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK) void k_icp_fixup(PassArgs a, GridParams gp, int row0) {
-  if (a.st->done) return;
-  __shared__ double red[O3D_BLOCK / O3D_WAVE][O3D_NSUMS];
-  __shared__ uint32_t list[kFixList];  // offsets from the block's first point
-  __shared__ uint32_t s_total;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
-  double acc[30];
-#pragma unroll
-  for (int k = 0; k < 30; k++) acc[k] = 0.0;
-  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + kFixTile - 1) / kFixTile * kFixTile;
-  const int64_t beg = (int64_t)blockIdx.x * per;
-  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
-  uint32_t fill = 0;  // entries in the list (block-uniform: every thread tracks it through s_total)
-  for (int64_t t0 = beg; t0 < end || fill > 0; t0 += kFixTile) {
-    const bool scanning = t0 < end;
-    if (scanning) {
-      // the first wave reads 64 pending-mask words (one per lane) and appends the set bits in index order
-      if (wave == 0) {
-        unsigned long long mask = 0;
-        if (t0 + 64 * (int64_t)lane < end) mask = a.pend[(t0 >> 6) + lane];
-        const uint32_t cnt = (uint32_t)__popcll(mask);
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int d = 1; d < O3D_WAVE; d <<= 1) {
-          const uint32_t o = __shfl_up(inc, d, O3D_WAVE);
-          if (lane >= d) inc += o;
-        }
-        uint32_t o = fill + inc - cnt;
-        const uint32_t off0 = (uint32_t)(t0 - beg) + 64u * (uint32_t)lane;
-        for (unsigned long long m = mask; m; m &= m - 1) list[o++] = off0 + (uint32_t)(__ffsll((long long)m) - 1);
-        if (lane == 63) s_total = fill + inc;
-      }
-      __syncthreads();
-      fill = s_total;
-    }
-    // search the gathered points once the list could overflow on the next step, or at the end of the slice
-    const bool flush = fill > 0 && (!scanning || t0 + kFixTile >= end || fill + kFixTile > kFixList);
-    if (flush) {
-      for (uint32_t q = threadIdx.x; q < fill; q += O3D_BLOCK) {
-        const int64_t i = beg + list[q];
-        const double x = a.src[3 * i], y = a.src[3 * i + 1], z = a.src[3 * i + 2];
-        Best b;
-        b.d2 = a.thr; b.idx = -1; b.pos = 0;
-        nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
-        a.corr[i] = (int32_t)b.idx;
-        a.pos[i] = b.pos;
-        if (b.idx >= 0) {
-          double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-          if (EST != O3D_EST_POINT_TO_POINT) {
-            n0 = a.nrm[3 * (size_t)b.pos]; n1 = a.nrm[3 * (size_t)b.pos + 1]; n2 = a.nrm[3 * (size_t)b.pos + 2];
-          }
-          if (EST == O3D_EST_COLORED_ICP)
-            accumulate_colored(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, a.tcol[b.pos], a.sint[i], a.slg, a.slp);
-          else
-            accumulate<EST>(acc, x, y, z, b, a.tgt[b.pos], n0, n1, n2, cx0, cy0, cz0);
-        }
-      }
-      fill = 0;
-    }
-    __syncthreads();
-    if (!scanning) break;
-  }
-  block_reduce_store(acc, red, a.partials, (unsigned)(row0 + blockIdx.x));
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -1431,7 +1402,7 @@ int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]) {
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   const bool prof = ctx->prof_on && ctx->prof_n < 340;
-  if (prof) {  // three events per pass: before the search, after it, after the fixup
+  if (prof) {  // three events per pass: before the search kernel, after it, after the accumulation kernel (alternative path)
     for (int k = 0; k < 3; k++)
       if (!ctx->prof_ev[3 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[3 * ctx->prof_n + k]));
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n], ctx->stream));
@@ -1442,7 +1413,6 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
-  pa.pend = ctx->pend_mask;
   pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
   const int est = ctx->estimation;
 #define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \
@@ -1454,22 +1424,19 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     else                                                                                                                   \
       hipLaunchKernelGGL(KERNEL<O3D_EST_POINT_TO_POINT>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);        \
   } while (0)
-  const int gf = O3D_FIX_GRID;
-  // Default: the cooperative fp32-prefilter search with the estimate's sums fused in, then the exact fixup of what it
-  // left undecided.  Alternative (grids too large for the fp32 error bound, or forced by o3d_debug_set): the per-lane
-  // fp64 search followed by the accumulation kernel.  Either way one partial row per workgroup, fixup rows behind.
+  // Default: ONE kernel per pass -- the cooperative fp32-prefilter search with the exact fp64 resolution of what fp32
+  // cannot decide and the estimate's sums fused in.  Alternative (grids too large for the fp32 error bound, or forced by
+  // o3d_debug_set): the per-lane fp64 search followed by the accumulation kernel.  One partial row per workgroup.
   const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
   const int grows = fused ? ctx->search_grid : ctx->pass_grid;
-  const int nparts = grows + gf;
+  const int nparts = grows;
   if (fused) {
     O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-    O3D_LAUNCH_EST(k_icp_fixup, gf, pa, ctx->gp, grows);
   } else {
     hipLaunchKernelGGL(k_icp_search, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
     O3D_LAUNCH_EST(k_icp_accumulate_mfma, grows, pa);
-    O3D_HIP(ctx, hipMemsetAsync(ctx->partials + (size_t)grows * O3D_NSUMS, 0, sizeof(double) * O3D_NSUMS * gf, ctx->stream));
   }
   if (prof) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 2], ctx->stream));
@@ -1519,6 +1486,17 @@ int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out) {
   hipLaunchKernelGGL(k_scatter_corr, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, ctx->corr_sorted, ctx->src_perm, ctx->n_src,
                      dev_out);
   O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+// Reads and clears the counter of failed confirmations (synchronises the stream).
+int o3d_take_bound_violations(o3d_ctx *ctx, unsigned int *out) {
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  O3D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bound_violations), sizeof(unsigned int)));
+  if (*out) {
+    const unsigned int z = 0;
+    O3D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bound_violations), &z, sizeof z));
+  }
   return O3D_OK;
 }
 

@@ -13,7 +13,6 @@
 #define O3D_NUM_CU 256
 #define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
 #define O3D_NSUMS 32
-#define O3D_FIX_GRID 512  // workgroups of k_icp_fixup (partial rows behind the pass rows)
 
 // ---- sums layout (per pass, fp64) -------------------------------------------
 // point-to-plane: [0..20] JTJ upper triangle row-major, [21..26] JTr, [27] sum r^2
@@ -78,7 +77,6 @@ struct o3d_ctx {
   int32_t *corr_sorted = nullptr;  // per processing position
   int32_t *corr_out = nullptr;     // caller's order (device staging)
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
-  unsigned long long *pend_mask = nullptr;  // one bit per processing position: left to k_icp_fixup
   size_t cap_src = 0;
   double *src_orig = nullptr;      // hypothesis mode: the source in processing order, never transformed
   size_t cap_src_orig = 0;
