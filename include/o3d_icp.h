@@ -197,16 +197,16 @@ O3D_API int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_transformation[16],
 O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows);
 /* HIP-event timing of the pass kernels on the context's stream.  enable != 0: every following pass is bracketed by HIP
  * events (at most 340 passes are kept).  o3d_icp_profile_read synchronises, returns the mean duration in milliseconds
- * of search + accumulation + fixup over the recorded passes and their number, and clears the record. */
+ * of the pass kernel(s) over the recorded passes and their number, and clears the record. */
 O3D_API int o3d_icp_profile(o3d_ctx *ctx, int enable);
 O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count);
-/* Same, split: out_mean_ms[0] = k_icp_search_coop (search with the estimate's sums fused in; k_icp_search on the
- * alternative path), [1] = k_icp_fixup (alternative path: k_icp_accumulate_mfma). */
+/* Same, split: out_mean_ms[0] = k_icp_search_coop (the one kernel of a pass; k_icp_search on the alternative path),
+ * [1] = k_icp_accumulate_mfma (alternative path only; otherwise ~0). */
 O3D_API int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count);
 /* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 search kernel +
  * accumulation kernel instead of the default cooperative fp32-prefilter search (both give the exact result);
- * collect_tile_stats != 0 makes the cooperative search count {wave trips, dense item trips, runs listed, points left to
- * the exact fixup, items, valid lanes} (process-wide counters, read by o3d_debug_tile_stats). */
+ * collect_tile_stats != 0 makes the cooperative search count {wave trips, dense item trips, runs listed, queries resolved
+ * by the exact fp64 search, items, valid lanes} (process-wide counters, read by o3d_debug_tile_stats). */
 O3D_API int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats);
 O3D_API int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset);
 /* Processing order of the source shard after o3d_icp_setup: out[p] = caller's index of the p-th processed point. */

@@ -1,11 +1,13 @@
 // The ICP iteration on the device.
 //
-//   k_icp_pass      one fused per-source-point kernel: pending update applied in place (Geometry3D.cpp:77-82), exact
-//                   radius-bounded nearest neighbour over the cell grid (KDTreeFlann::SearchHybrid with max_nn = 1,
-//                   geometry/KDTreeFlann.cpp:132-152, as used by Registration.cpp:60-68), correspondence index out, and
-//                   the per-thread fp64 accumulation of the NEXT estimate's sums (utility/Eigen.cpp:180-185 with the
-//                   lambda of TransformationEstimation.cpp:79-86, or the Umeyama moments of :53-59), reduced by wavefront
-//                   shuffles and an LDS tree to one 32-double partial per workgroup.
+//   k_icp_search_coop  ONE kernel per pass: pending update applied in place (Geometry3D.cpp:77-82), exact radius-bounded
+//                   nearest neighbour over the cell grid (KDTreeFlann::SearchHybrid with max_nn = 1,
+//                   geometry/KDTreeFlann.cpp:132-152, as used by Registration.cpp:60-68) -- fp32 prefilter over a
+//                   wave-cooperative work queue, fp64 confirmation, exact fp64 resolution of what fp32 cannot decide --
+//                   correspondence index out, and the NEXT estimate's sums (utility/Eigen.cpp:180-185 with the lambda of
+//                   TransformationEstimation.cpp:79-86, the Umeyama moments of :53-59, or the two rows of
+//                   ColoredICP.cpp:136-165) as fp64 MFMA rank-4 updates, one 32-double partial row per workgroup.
+//   k_icp_search + k_icp_accumulate_mfma   the alternative path: per-lane fp64 search, then the sums.
 //   k_icp_finalize  fixed-order sum of the workgroup partials -> this shard's 32 sums (run-to-run deterministic).
 //   k_icp_solve     one lane: sum over ranks in rank order, fitness / rmse (Registration.cpp:82-89), convergence test
 //                   (:162-165), 6x6 pivoted LDLT (utility/Eigen.cpp:85,116-130) or Umeyama + 3x3 Jacobi SVD, Rz*Ry*Rx
@@ -221,7 +223,7 @@ __device__ __forceinline__ void colored_rows(double x, double y, double z, const
   rp = slp * (is - is0);
 }
 
-// per-lane form of the coloured sums (k_icp_fixup): same layout as point-to-plane
+// per-lane form of the coloured sums: same layout as point-to-plane
 __device__ __forceinline__ void accumulate_colored(double (&acc)[30], double x, double y, double z, const Best &b, const double4 &p,
                                                    double n0, double n1, double n2, const double4 &tc, double is, double slg,
                                                    double slp) {
@@ -260,7 +262,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
 }
 
 // Optional counters of the cooperative search (tests and tuning): [0] wave trips, [1] dense item trips, [2] runs
-// listed, [3] lanes left to the exact fixup, [4] items (four candidates each), [5] valid lanes.
+// listed, [3] queries resolved by the exact fp64 search, [4] items (four candidates each), [5] valid lanes.
 __device__ unsigned long long g_tile_stats[8];
 // number of fp32 winners whose fp64 confirmation failed (must stay 0: see k_icp_search_coop)
 __device__ unsigned int g_bound_violations;
@@ -275,7 +277,7 @@ struct PassArgs {
   const double *nrm;
   const uint32_t *cell_start;
   const IcpState *st;
-  int32_t *corr;   // per processing position: target index, -1 none, -2 left to k_icp_fixup, -3 unconfirmed candidate at pos
+  int32_t *corr;   // per processing position: target index, or -1 none
   uint32_t *pos;   // per processing position: position of the match in tgt_sorted
   double *partials;
   double thr;
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
 //   * the lane keeps the best and the second-best fp32 distance.  The winner is handed to k_icp_accumulate, which
 //     confirms it in fp64 with the arithmetic of the exact search.  When the fp32 result is not decisive -- runner-up
 //     within the fp32 error bound of the winner, winner within the bound of the acceptance threshold, query outside
-//     the grid -- the point is left to k_icp_fixup's exact fp64 search.  The result is therefore always the exact
+//     the grid -- the point is searched again exactly in fp64 (wave_exact_search).  The result is therefore always the exact
 //     argmin over (d2, index).
 // fp32 error budget (h = cell size): candidate and query coordinates are formed relative to the query's cell origin with
 // magnitude <= 2h; each is within 4e-7 h of its exact value, so |d2_fp32 - d2| <= 1.6e-6 h^2 for every candidate of
@@ -571,7 +573,7 @@ __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_
 // (wave prefix sum over the lanes' item counts), and the 64 lanes process the queue densely: lane k takes item k, k + 64,
 // ... whoever owns it.  An item's result is merged into its owner's (best, second-best) pair with LDS atomics; the
 // streaming top-2 rule -- the larger of (incoming, previous best) goes to `second` -- is independent of the order in
-// which the atomics land.  Same verdicts as the per-lane kernel: what is not decisive in fp32 goes to the exact fixup.
+// which the atomics land.  What is not decisive in fp32 is searched again exactly in fp64 on the spot.
 constexpr int kQCap = 256;            // items per wavefront and round (mean demand is ~260; more rounds when it overflows)
 constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
 constexpr uint32_t kRunMaxLen = 1u << 28;
@@ -885,20 +887,22 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
-// partials[b][k] for b = g, g + 32, ... (coalesced over k), the 32 group sums are then added in group order.
+// partials[b][k] for b = g, g + 32, ... (coalesced over k, eight rows in flight), the 32 group sums are then added in
+// group order.
 #define O3D_FIN_THREADS 1024
 __device__ __forceinline__ void finalize_sums(const double *__restrict__ partials, int nparts, double (*s)[O3D_NSUMS]) {
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;  // four independent chains: the row loads overlap
-  int b = g;
-  for (; b + 96 < nparts; b += 128) {
-    v0 += partials[(size_t)b * O3D_NSUMS + k];
-    v1 += partials[(size_t)(b + 32) * O3D_NSUMS + k];
-    v2 += partials[(size_t)(b + 64) * O3D_NSUMS + k];
-    v3 += partials[(size_t)(b + 96) * O3D_NSUMS + k];
+  double acc = 0.0;  // eight independent row loads per step (the order of the additions is fixed by the indices alone)
+  for (int b0 = g; b0 < nparts; b0 += 32 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int b = b0 + 32 * u;
+      v[u] = b < nparts ? partials[(size_t)b * O3D_NSUMS + k] : 0.0;
+    }
+    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
-  for (; b < nparts; b += 32) v0 += partials[(size_t)b * O3D_NSUMS + k];
-  s[g][k] = (v0 + v1) + (v2 + v3);
+  s[g][k] = acc;
   __syncthreads();
   if (threadIdx.x < O3D_NSUMS) {
     double t = s[0][k];
