@@ -192,6 +192,15 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch,
             },
         }
+        # HBM traffic per launch from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be read
+        # from inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; nearly all reads
+        # here are 16-byte loads) + WRITE_SIZE.  Only quoted for the workload it was collected on.
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if world == 1 and n == 10_000_000 and args.estimation == "p2plane" and args.search == "f32" and os.path.exists(tpath):
+            with open(tpath) as f:
+                tr = json.load(f)
+            out["roofline"]["traffic"] = (2.0 * tr["fetch_size_kb"] + tr["write_size_kb"]) * 1024.0
+            out["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, normals, radius, min(args.cpu_sample, n), args.cpu_iters)
         print(json.dumps(out))
