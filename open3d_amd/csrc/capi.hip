@@ -315,6 +315,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
   }
   ctx->search_grid = (int)gs;
+  ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
   const int rows = max_iter + 1;
   if (rows > ctx->log_rows || !ctx->log) {
     if (ctx->log) (void)hipFree(ctx->log);

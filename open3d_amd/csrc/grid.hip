@@ -362,6 +362,7 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;
+  O3D_HIP(ctx, hipMemsetAsync(ctx->pos_sorted, 0xFF, sizeof(uint32_t) * (size_t)n, ctx->stream));  // no previous match
   const size_t ntiles = o3d_sort_num_tiles(n);
   const size_t nh = 256 * ntiles;
   void *keys, *tkeys, *tvals, *hist, *dT;

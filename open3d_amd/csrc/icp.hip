@@ -278,7 +278,8 @@ struct PassArgs {
   const uint32_t *cell_start;
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, or -1 none
-  uint32_t *pos;   // per processing position: position of the match in tgt_sorted
+  uint32_t *pos;   // per processing position: position of the match in tgt_sorted (O3D_POS_NONE: none)
+  int seed;        // k_icp_search_coop: use the previous pass's match as the first pruning bound
   double *partials;
   double thr;
   // coloured ICP only (ColoredICP.cpp:125-177)
@@ -287,6 +288,7 @@ struct PassArgs {
   double slg, slp;      // sqrt(lambda_geometric), sqrt(1 - lambda_geometric)
 };
 #define O3D_CORR_NONE (-1)
+#define O3D_POS_NONE 0xFFFFFFFFu
 #define O3D_CORR_PENDING (-2)
 #define O3D_CORR_CANDIDATE (-3)
 
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams
     b.d2 = a.thr; b.idx = -1; b.pos = 0;
     nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
     a.corr[i] = (int32_t)b.idx;
-    a.pos[i] = b.pos;
+    a.pos[i] = b.idx >= 0 ? b.pos : O3D_POS_NONE;
   }
 }
 
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
 // the block (d2 <= 12 h^2 is irrelevant beyond ~h^2).  kF32Err = 4e-6 (x h^2) is used as the bound e: "decisive" means
 // second - best > 2e and |best - thr| > e; runs are pruned only when their face distance exceeds best + 4e.
 constexpr float kF32Err = 4e-6f;
+constexpr float kSeedMax = 0.5f;   // a seed farther than sqrt(kSeedMax) cells prunes worse than the centre-cell phase
 constexpr int kMaxRuns = 10;  // left cell, right cell, eight neighbouring rows
 
 // Four consecutive cell-table entries in one 16-byte load (the table is only 4-byte aligned at an arbitrary cell:
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
   const float margin = 1e-5f * hf;
+  const float seed_max = kSeedMax * hf * hf;
   const float4 *__restrict__ tl = a.tgt_local;
   const uint32_t *__restrict__ cs = a.cell_start;
   const unsigned long long kBestInit = (unsigned long long)0x7F800000u << 32;  // +inf, position 0
@@ -749,8 +753,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     const int64_t i = base + tid;
     const bool valid = i < end;
     double x = 0, y = 0, z = 0;
+    uint32_t pprev = O3D_POS_NONE;
     if (valid) {
       x = a.src_in[3 * i]; y = a.src_in[3 * i + 1]; z = a.src_in[3 * i + 2];
+      if (a.seed) pprev = a.pos[i];
     }
     if (valid && apply) {
       apply_update(T, w, x, y, z);
@@ -772,16 +778,29 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       const CellQuad qc = *reinterpret_cast<const CellQuad *>(rowp);
       s0 = qc.v[0]; s1 = qc.v[1]; s2 = qc.v[2]; s3 = qc.v[3];
     }
-    if (base != beg) consume();  // the previous trip's matches, behind this trip's source and table loads
+    // Seed: the target point this query matched in the previous pass.  Any target point bounds the nearest-neighbour
+    // distance from above; near convergence the previous match is (nearly) the nearest, so its exact distance prunes
+    // the block from the start and the centre-cell phase is skipped.  Only a bound: every cell it leaves is scanned and
+    // the winner comes out of the scan as always.
+    const bool has_seed = inside && pprev != O3D_POS_NONE;
+    double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (has_seed) ps = a.tgt[pprev];
+    if (base != beg) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
     bool too_long = s3 - s0 >= kRunMaxLen;
-    // phase 1: the centre cells of the wavefront's queries
+    float seedb = INFINITY;
+    if (has_seed) {
+      const double ddx = x - ps.x, ddy = y - ps.y, ddz = z - ps.z;
+      seedb = (float)(ddx * ddx + ddy * ddy + ddz * ddz) * 1.000001f + err;  // >= the exact distance, in fp32
+    }
+    const bool seeded = seedb <= seed_max && !too_long;
+    // phase 1: the centre cells of the wavefront's queries that have no usable seed
     wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(cx + 1));
     wl.best[lane] = kBestInit;
     wl.second[lane] = 0x7F800000u;
-    wl.runs[kCentreSlot][lane] = make_run(s1, too_long ? s1 : s2, 0, 0);
+    wl.runs[kCentreSlot][lane] = make_run(s1, (too_long || seeded) ? s1 : s2, 0, 0);
     wave_lds_sync();
-    unsigned trips = coop_phase(wl, lane, kCentreSlot, too_long ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
-    const float best1 = __uint_as_float((uint32_t)(wl.best[lane] >> 32));
+    unsigned trips = coop_phase(wl, lane, kCentreSlot, (too_long || seeded) ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
+    const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
     // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
     // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
     // together), instead of eight loads per query up front.
@@ -805,8 +824,13 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
         const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
         if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
       }
-      if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
-      if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
+      if (seeded) {  // centre row in one run: centre cell, and the left / right cell where the bound reaches them
+        const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
+        if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
+      } else {
+        if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
+        if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
+      }
 #pragma unroll
       for (int r = 0; r < 9; r++) {
         if (r == 4) continue;
@@ -826,7 +850,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     }
     wave_lds_sync();
     trips += coop_phase(wl, lane, 0, tot, tl, hf);
-    uint32_t bpos = 0;
+    uint32_t bpos = O3D_POS_NONE;
     if (inside) {
       const unsigned long long bb = wl.best[lane];
       const float best = __uint_as_float((uint32_t)(bb >> 32)), second = __uint_as_float(wl.second[lane]);
@@ -877,7 +901,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     }
     if (valid) {
       if (!use_p) a.corr[i] = verdict;  // a candidate's entry is written when it is confirmed
-      a.pos[i] = bpos;
+      a.pos[i] = use_p ? bpos : O3D_POS_NONE;
     }
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
@@ -1417,6 +1441,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
+  pa.seed = ctx->use_seed;
   pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
   const int est = ctx->estimation;
 #define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \

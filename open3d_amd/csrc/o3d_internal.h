@@ -95,6 +95,7 @@ struct o3d_ctx {
   int log_rows = 0;
   int pass_grid = 0;    // workgroups of the accumulate / per-lane search kernels (one partial row each)
   int search_grid = 0;  // workgroups of k_icp_search_coop
+  int use_seed = 1;     // k_icp_search_coop: previous match as the first pruning bound (O3D_NO_SEED=1 turns it off)
   int icp_ready = 0;
   int max_iter = 0;
   int enq_passes = 0;
