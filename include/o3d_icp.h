@@ -246,7 +246,7 @@ O3D_API int o3d_radius_neighbor_count(o3d_ctx *ctx, const double *xyz, int64_t n
 O3D_API int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_neighbors, int mem, double *out_mean);
 
 /* ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159 (SPFH :71-111, pair features :39-69).  search_type KNN
- * or HYBRID (knn / max_nn <= 64).  out_feature: 33 doubles per point, the storage of Feature::data_ (33 x n, column-major). */
+ * or HYBRID (knn / max_nn <= 128).  out_feature: 33 doubles per point, the storage of Feature::data_ (33 x n, column-major). */
 O3D_API int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *normals, int64_t n, int search_type, int knn,
                              double radius, int mem, double *out_feature);
 

@@ -222,7 +222,15 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 }
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
-constexpr int kMaxKnn = 64;
+constexpr int kMaxKnn = 128;  // 16 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
+
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel.
+template <typename K>
+int allow_lds(o3d_ctx *ctx, K kernel, size_t lds) {
+  if (lds > 65536)
+    O3D_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return O3D_OK;
+}
 
 // k-best list of one lane, ascending by (d2, index) -- the order FLANN returns and ComputeNormal sums in.
 struct KList {
@@ -827,15 +835,19 @@ int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int se
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
     if (ng > 0) {
       if (degenerate) {
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
                            ctx->cell_start, ctx->gp, 1, 0.0, d_nrm, has_normals);
       } else if (search_type == O3D_SEARCH_KNN) {
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
                            ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
       } else if (search_type == O3D_SEARCH_RADIUS) {
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<1>, lds));
         hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
                            ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
       } else {
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
                            ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
       }
@@ -976,6 +988,7 @@ int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_n
   const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)max_nn;
   int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
   g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+  O3D_TRY(allow_lds(ctx, k_color_gradient, lds));
   hipLaunchKernelGGL(k_color_gradient, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp,
                      max_nn, thr, d_nrm, d_col, d_grad);
   O3D_HIP(ctx, hipGetLastError());
@@ -1030,6 +1043,9 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
     int64_t g = (n_q + kNrmBlock - 1) / kNrmBlock;
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
     const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126
+    O3D_TRY(allow_lds(ctx, k_neighbor_query<0>, lds));
+    O3D_TRY(allow_lds(ctx, k_neighbor_query<1>, lds));
+    O3D_TRY(allow_lds(ctx, k_neighbor_query<2>, lds));
     if (mode == 0)
       hipLaunchKernelGGL(k_neighbor_query<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ctx->cell_start, ctx->gp,
                          d_q, n_q, kk, thr, (double *)d_out, (int32_t *)nullptr);
@@ -1097,8 +1113,10 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
       const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)knn;
       int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
       g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+      O3D_TRY(allow_lds(ctx, k_fpfh<0>, lds));
       hipLaunchKernelGGL(k_fpfh<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
                          thr, knn_mode ? 1 : 0, d_nrm, (const double *)nullptr, (double *)sp);
+      O3D_TRY(allow_lds(ctx, k_fpfh<1>, lds));
       hipLaunchKernelGGL(k_fpfh<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
                          thr, knn_mode ? 1 : 0, d_nrm, (const double *)sp, d_out);
       O3D_HIP(ctx, hipGetLastError());

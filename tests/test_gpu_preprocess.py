@@ -230,6 +230,25 @@ def test_fpfh_matches_oracle(ctx, oracle, mode):
     assert bad.sum() <= max(3, len(pts) // 2000), "too many points differ: %d" % bad.sum()
 
 
+def test_large_neighbourhoods_up_to_128(ctx, oracle):
+    """max_nn = 100 (the usual FPFH parameter, Hybrid(5 voxels, 100)) and knn = 128: lists beyond 64 KiB of LDS."""
+    from open3d_amd import geometry, _lib
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(100, 6000, cfg_id=35)
+    s, pts = sc["spacing"], sc["target"]
+    nrm = oracle.estimate_normals(pts, oracle.HYBRID, 30, 4 * s)
+    pc = geometry.PointCloud(pts, normals=nrm)
+    got = reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamHybrid(8 * s, 100), ctx=ctx)
+    ref = oracle.fpfh(pts, nrm, oracle.HYBRID, 100, 8 * s)
+    bad = np.abs(got.data_.T - ref).max(1) > 1e-9 * 100.0
+    assert bad.sum() <= 3, "too many points differ: %d" % bad.sum()
+    pn = geometry.PointCloud(pts)
+    pn.EstimateNormals(geometry.KDTreeSearchParamKNN(128), ctx=ctx)
+    assert _normals_close(pn.normals_, oracle.estimate_normals(pts, oracle.KNN, 128, 0.0)).mean() > 0.999
+    with pytest.raises(_lib.O3DError):
+        pn.EstimateNormals(geometry.KDTreeSearchParamKNN(129), ctx=ctx)   # beyond the LDS lists: refused, not truncated
+
+
 def test_fpfh_edge_cases(ctx):
     from open3d_amd import geometry, _lib
     from open3d_amd.pipelines import registration as reg
