@@ -911,20 +911,24 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
-// partials[b][k] for b = g, g + 32, ... (coalesced over k, eight rows in flight), the 32 group sums are then added in
+// partials[b][k] for b = g, g + 32, ... (coalesced over k, 32 rows in flight), the 32 group sums are then added in
 // group order.
 #define O3D_FIN_THREADS 1024
 __device__ __forceinline__ void finalize_sums(const double *__restrict__ partials, int nparts, double (*s)[O3D_NSUMS]) {
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-  double acc = 0.0;  // eight independent row loads per step (the order of the additions is fixed by the indices alone)
-  for (int b0 = g; b0 < nparts; b0 += 32 * 8) {
-    double v[8];
+  double acc = 0.0;  // 32 independent row loads per step (the order of the additions is fixed by the indices alone)
+  for (int b0 = g; b0 < nparts; b0 += 32 * 32) {
+    double v[32];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < 32; u++) {
       const int b = b0 + 32 * u;
       v[u] = b < nparts ? partials[(size_t)b * O3D_NSUMS + k] : 0.0;
     }
-    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int w = 1; w < 32; w <<= 1)
+#pragma unroll
+      for (int u = 0; u < 32; u += 2 * w) v[u] += v[u + w];
+    acc += v[0];
   }
   s[g][k] = acc;
   __syncthreads();
@@ -968,10 +972,16 @@ __device__ void mat4_mul(const double *A, const double *B, double *C) {
 
 // x = A^-1 b by LDL^T with symmetric pivoting on the largest |diagonal| (Eigen::LDLT semantics, utility/Eigen.cpp:85):
 // lower triangle only, zero pivot -> zero component.
-__device__ void ldlt_solve6(const double *A, const double *b, double *x) {
-  const int n = 6;
-  double M[36];
+// The pivoting indexes M, y and tr dynamically: they live in the caller's LDS workspace (private arrays would go to scratch
+// memory, a microsecond per dependent access).
+struct SolveWork {
+  double M[36], y[6], temp[6];
   int tr[6];
+};
+__device__ void ldlt_solve6(const double *A, const double *b, double *x, SolveWork &wk) {
+  const int n = 6;
+  double *M = wk.M, *y = wk.y, *temp = wk.temp;
+  int *tr = wk.tr;
   for (int i = 0; i < 36; i++) M[i] = A[i];
 #define MM(i, j) M[(i) * 6 + (j)]
   for (int k = 0; k < n; k++) {
@@ -987,7 +997,6 @@ __device__ void ldlt_solve6(const double *A, const double *b, double *x) {
       double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t;
     }
     if (k > 0) {
-      double temp[6];
       for (int j = 0; j < k; j++) temp[j] = MM(j, j) * MM(k, j);
       double s = 0;
       for (int j = 0; j < k; j++) s += MM(k, j) * temp[j];
@@ -1002,7 +1011,6 @@ __device__ void ldlt_solve6(const double *A, const double *b, double *x) {
     if (fabs(akk) > 0)
       for (int i = k + 1; i < n; i++) MM(i, k) /= akk;
   }
-  double y[6];
   for (int i = 0; i < n; i++) y[i] = b[i];
   for (int k = 0; k < n; k++)
     if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
@@ -1143,7 +1151,8 @@ __device__ void umeyama_from_sums(const double *q, const double *centre, int wit
 }
 
 // One lane: everything between two passes of Registration.cpp:155-166.
-__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
+__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows,
+                           SolveWork &wk) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
   if (nc > 0.0) {  // Registration.cpp:82-89
@@ -1176,7 +1185,7 @@ __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_n
         for (int a = 0; a < 6; a++)
           for (int c = a; c < 6; c++) { A[a * 6 + c] = q[k]; A[c * 6 + a] = q[k]; k++; }
         for (int a = 0; a < 6; a++) b[a] = -q[21 + a];
-        ldlt_solve6(A, b, x);
+        ldlt_solve6(A, b, x, wk);
         vec6_to_mat4(x, upd);
       }
     } else {
@@ -1188,17 +1197,31 @@ __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_n
   st->apply_update = 1;
 }
 
+// The loop state is staged in LDS for the one lane that runs the estimate (dozens of dependent global accesses otherwise)
+// and written back by the workgroup.
+static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied word by word");
+__device__ __forceinline__ void state_copy(uint32_t *dst, const uint32_t *src) {
+  for (unsigned k = threadIdx.x; k < sizeof(IcpState) / 4; k += blockDim.x) dst[k] = src[k];
+}
+
+// Sharded loop: launched with one wavefront; sums the ranks' rows in rank order, then the estimate.
 __global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict__ all_sums, int n_ranks, int has_normals,
                             double *__restrict__ log, int log_rows) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
   if (st->done) return;
-  double q[O3D_NSUMS];
-  for (int k = 0; k < O3D_NSUMS; k++) {
+  __shared__ IcpState ls;
+  __shared__ SolveWork wk;
+  __shared__ double q[O3D_NSUMS];
+  state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(st));
+  for (int k = threadIdx.x; k < O3D_NSUMS; k += blockDim.x) {
     double v = all_sums[k];
     for (int r = 1; r < n_ranks; r++) v += all_sums[(size_t)r * O3D_NSUMS + k];
     q[k] = v;
   }
-  solve_body(st, q, has_normals, log, log_rows);
+  __syncthreads();
+  if (threadIdx.x == 0) solve_body(&ls, q, has_normals, log, log_rows, wk);
+  __syncthreads();
+  state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
 }
 
 // Unsharded loop: partial reduction and estimate in one launch.
@@ -1207,13 +1230,14 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize_solve(const do
                                                                          int has_normals, double *__restrict__ log, int log_rows) {
   if (st->done) return;
   __shared__ double s[32][O3D_NSUMS];
+  __shared__ IcpState ls;
+  __shared__ SolveWork wk;
+  state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(st));
   finalize_sums(partials, nparts, s);
   if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
-  if (threadIdx.x == 0) {
-    double q[O3D_NSUMS];
-    for (int k = 0; k < O3D_NSUMS; k++) q[k] = s[0][k];
-    solve_body(st, q, has_normals, log, log_rows);
-  }
+  if (threadIdx.x == 0) solve_body(&ls, s[0], has_normals, log, log_rows, wk);
+  __syncthreads();
+  state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
 }
 
 __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__restrict__ corr_sorted, const uint32_t *__restrict__ perm,
@@ -1313,6 +1337,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_pairs_accumulate(PairArgs a) {
 __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, int nparts, int estimation, int with_scaling,
                                                                      double *__restrict__ out) {
   __shared__ double s[32][O3D_NSUMS];
+  __shared__ SolveWork wk;
   finalize_sums(a.partials, nparts, s);
   if (threadIdx.x != 0) return;
   double q[O3D_NSUMS];
@@ -1330,7 +1355,7 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, 
         for (int r = 0; r < 6; r++)
           for (int c = r; c < 6; c++) { A[r * 6 + c] = q[k]; A[c * 6 + r] = q[k]; k++; }
         for (int r = 0; r < 6; r++) b[r] = -q[21 + r];
-        ldlt_solve6(A, b, x);
+        ldlt_solve6(A, b, x, wk);
         vec6_to_mat4(x, T);
       }
     } else {

@@ -51,7 +51,7 @@ class HipEngine:
 class ShardedICP:
     """RegistrationICP (reference Registration.cpp:129-168) with the source cloud sharded over a process group."""
 
-    def __init__(self, engine, group=None, device=None):
+    def __init__(self, engine, group=None, device=None, force_exchange=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -63,6 +63,8 @@ class ShardedICP:
         self.local = torch.zeros(NSUMS, dtype=torch.float64, device=self.device)
         self.all = torch.zeros(NSUMS * self.world, dtype=torch.float64, device=self.device)
         self.max_iter = 0
+        # run the pass -> all-gather -> solve sequence even with one rank (rehearses the N > 1 path on one GPU)
+        self.force_exchange = bool(force_exchange) and dist.is_initialized()
 
     def setup(self, src_shard, tgt, tgt_normals, max_dist, init, estimation, criteria, n_src_global):
         self.max_iter = criteria.max_iteration_
@@ -70,11 +72,11 @@ class ShardedICP:
 
     def step(self):
         """One LOOP-A pass + estimate on every rank (enqueue only; no host synchronisation)."""
-        if self.world == 1 and hasattr(self.engine, "step_unsharded"):
+        if self.world == 1 and not self.force_exchange and hasattr(self.engine, "step_unsharded"):
             self.engine.step_unsharded()
             return
         self.engine.pass_into(self.local)
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             self.dist.all_gather_into_tensor(self.all, self.local, group=self.group)
             self.engine.solve_from(self.all, self.world)
         else:

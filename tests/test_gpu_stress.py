@@ -111,3 +111,23 @@ def test_headline_size_10m_properties(ctx, oracle):
     assert np.array_equal(got_p.corr_, got.corr_[perm])
     assert got_p.fitness_ == got.fitness_
     assert np.abs(got_p.transformation_ - T).max() < 1e-12 and abs(got_p.inlier_rmse_ - got.inlier_rmse_) < 1e-15
+
+
+@pytest.mark.gpu
+def test_bench_exchange_path_under_torchrun_one_rank():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL process group), rehearsed with one rank on
+    the one GPU of the box: pass -> all-gather of the 32 sums over RCCL -> solve must give the numbers of the unsharded loop."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--points", "200000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "bench.py")] + common + ["--force-exchange"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja, jb = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) for r in (a, b))
+    assert ja["n_gpus"] == 1 and ja["value"] > 0
+    for k in ("fitness", "inlier_rmse", "n_corr"):
+        assert ja["config"][k] == pytest.approx(jb["config"][k], rel=1e-12), k
