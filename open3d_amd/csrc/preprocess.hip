@@ -232,7 +232,10 @@ int allow_lds(o3d_ctx *ctx, K kernel, size_t lds) {
   return O3D_OK;
 }
 
-// k-best list of one lane, ascending by (d2, index) -- the order FLANN returns and ComputeNormal sums in.
+// k-best list of one lane.  While candidates arrive it is a binary MAX-heap on (d2, index) -- the worst kept entry is the
+// root, an insertion moves at most log2(k) entries (a sorted list moves k/2 on average and, lanes inserting at different
+// places, nearly k per wavefront step) -- and klist_sort turns it in place into the ascending order FLANN returns and
+// ComputeNormal sums in.
 struct KList {
   double *d2;     // LDS, stride kNrmBlock
   uint32_t *pos;  // LDS, stride kNrmBlock: position in tgt_sorted
@@ -241,33 +244,71 @@ struct KList {
   double thr;     // strict bound on d2 (INFINITY for pure KNN)
 };
 
-__device__ __forceinline__ double klist_worst(const KList &l) {
-  return (l.count == l.cap) ? l.d2[(l.cap - 1) * kNrmBlock] : l.thr;
+__device__ __forceinline__ bool kl_less(double d1, uint32_t i1, double d2, uint32_t i2) {
+  return d1 < d2 || (d1 == d2 && i1 < i2);
 }
 
-__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t id, uint32_t pos) {
-  if (!(d < l.thr)) return;
-  int i;
-  if (l.count == l.cap) {
-    const double wd = l.d2[(l.cap - 1) * kNrmBlock];
-    const uint32_t wi = l.idx[(l.cap - 1) * kNrmBlock];
-    if (!(d < wd || (d == wd && id < wi))) return;
-    i = l.cap - 1;
-  } else {
-    i = l.count++;
-  }
-  while (i > 0) {
-    const double pd = l.d2[(i - 1) * kNrmBlock];
-    const uint32_t pi = l.idx[(i - 1) * kNrmBlock];
-    if (!(d < pd || (d == pd && id < pi))) break;
-    l.d2[i * kNrmBlock] = pd;
-    l.idx[i * kNrmBlock] = pi;
-    l.pos[i * kNrmBlock] = l.pos[(i - 1) * kNrmBlock];
-    i--;
+__device__ __forceinline__ double klist_worst(const KList &l) {
+  return (l.count == l.cap) ? l.d2[0] : l.thr;
+}
+
+// Put (d, id, pos) into the hole at the root of the heap of `n` entries and let it sink.
+__device__ __forceinline__ void klist_sink(KList &l, int n, double d, uint32_t id, uint32_t pos) {
+  int i = 0;
+  for (;;) {
+    int c = 2 * i + 1;
+    if (c >= n) break;
+    double cd = l.d2[c * kNrmBlock];
+    uint32_t ci = l.idx[c * kNrmBlock];
+    if (c + 1 < n) {
+      const double rd = l.d2[(c + 1) * kNrmBlock];
+      const uint32_t ri = l.idx[(c + 1) * kNrmBlock];
+      if (kl_less(cd, ci, rd, ri)) { c++; cd = rd; ci = ri; }
+    }
+    if (!kl_less(d, id, cd, ci)) break;
+    l.d2[i * kNrmBlock] = cd;
+    l.idx[i * kNrmBlock] = ci;
+    l.pos[i * kNrmBlock] = l.pos[c * kNrmBlock];
+    i = c;
   }
   l.d2[i * kNrmBlock] = d;
   l.idx[i * kNrmBlock] = id;
   l.pos[i * kNrmBlock] = pos;
+}
+
+__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t id, uint32_t pos) {
+  if (!(d < l.thr)) return;
+  if (l.count == l.cap) {  // replace the worst entry if the candidate is better
+    if (!kl_less(d, id, l.d2[0], l.idx[0])) return;
+    klist_sink(l, l.cap, d, id, pos);
+    return;
+  }
+  int i = l.count++;
+  while (i > 0) {  // rise
+    const int p = (i - 1) >> 1;
+    const double pd = l.d2[p * kNrmBlock];
+    const uint32_t pi = l.idx[p * kNrmBlock];
+    if (!kl_less(pd, pi, d, id)) break;
+    l.d2[i * kNrmBlock] = pd;
+    l.idx[i * kNrmBlock] = pi;
+    l.pos[i * kNrmBlock] = l.pos[p * kNrmBlock];
+    i = p;
+  }
+  l.d2[i * kNrmBlock] = d;
+  l.idx[i * kNrmBlock] = id;
+  l.pos[i * kNrmBlock] = pos;
+}
+
+// Heap -> ascending by (d2, index), in place.  Call once, after the last klist_add and before reading the entries in order.
+__device__ __forceinline__ void klist_sort(KList &l) {
+  for (int end = l.count - 1; end > 0; end--) {
+    const double d = l.d2[end * kNrmBlock];
+    const uint32_t id = l.idx[end * kNrmBlock], pos = l.pos[end * kNrmBlock];
+    l.d2[end * kNrmBlock] = l.d2[0];
+    l.idx[end * kNrmBlock] = l.idx[0];
+    l.pos[end * kNrmBlock] = l.pos[0];
+    klist_sink(l, end, d, id, pos);
+  }
 }
 
 // Per point: neighbours by KNN / radius / hybrid search over the cloud's own cell grid, cumulants in neighbour order,
@@ -318,21 +359,29 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
             xa = max(xa, -1); xb = min(xb, gp.nx);
             if (xa > xb) continue;
             const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-            for (uint32_t j = s; j < e; j++) {
-              const double4 t = pts[j];
-              const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
-              double d2 = ddx * ddx;
-              d2 = d2 + ddy * ddy;
-              d2 = d2 + ddz * ddz;
-              if (MODE == 1) {
-                if (d2 < thr) {
-                  count++;
-                  c[0] += t.x; c[1] += t.y; c[2] += t.z;
-                  c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
-                  c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+            for (uint32_t j0 = s; j0 < e; j0 += 4) {  // four candidate loads in flight; processed in run order
+              double4 tq[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + (uint32_t)u;
+                if (j >= e) break;
+                const double4 t = tq[u];
+                const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+                double d2 = ddx * ddx;
+                d2 = d2 + ddy * ddy;
+                d2 = d2 + ddz * ddz;
+                if (MODE == 1) {
+                  if (d2 < thr) {
+                    count++;
+                    c[0] += t.x; c[1] += t.y; c[2] += t.z;
+                    c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+                    c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+                  }
+                } else if (d2 <= klist_worst(l)) {
+                  klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
                 }
-              } else if (d2 <= klist_worst(l)) {
-                klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
               }
             }
           }
@@ -348,6 +397,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
     }
     int k = count;
     if (MODE != 1) {
+      klist_sort(l);
       k = l.count;
       for (int i = 0; i < k; i++) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
         const double4 t = pts[l.pos[i * kNrmBlock]];
@@ -475,6 +525,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
       }
     }
     double g[3] = {0.0, 0.0, 0.0};
+    klist_sort(l);
     const int nn = l.count;
     if (nn >= 4) {
       const double n0 = normals[3 * qi], n1 = normals[3 * qi + 1], n2 = normals[3 * qi + 2];
@@ -571,11 +622,12 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
         if (klist_worst(l) <= reach * reach) break;
       }
     }
-    if (MODE == 0) {
-      out[i] = (l.count >= knn) ? sqrt(l.d2[(knn - 1) * kNrmBlock]) : 0.0;
+    if (MODE == 0) {  // the k-th distance is the worst kept entry: the heap's root
+      out[i] = (l.count >= knn) ? sqrt(l.d2[0]) : 0.0;
     } else if (MODE == 1) {
       double mean = -1.0;
       if (l.count > 0) {
+        klist_sort(l);
         double sum = 0.0;  // std::accumulate over the ascending distances (PointCloud.cpp:445-446)
         for (int k = 0; k < l.count; k++) sum += sqrt(l.d2[k * kNrmBlock]);
         mean = sum / (double)l.count;
@@ -635,6 +687,7 @@ __device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__res
       if (klist_worst(l) <= reach * reach) break;
     }
   }
+  klist_sort(l);
 }
 
 // ComputePairFeatures, Feature.cpp:39-69
