@@ -250,6 +250,42 @@ O3D_API int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, in
 O3D_API int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *normals, int64_t n, int search_type, int knn,
                              double radius, int mem, double *out_feature);
 
+/* The feature-space nearest neighbour of RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:223,237
+ * (KDTreeFlann over the target Feature, SearchKNN(column, 1): geometry/KDTreeFlann.cpp:93-110): for every query the target
+ * column with the smallest flann::L2<double> distance (4-wide groups, then the tail), ties to the lowest
+ * index.  Features are `dim` doubles per point (Feature::data_, dim x n column-major).  query_ids (n_q indices into the
+ * source features, same memory space as the data) may be NULL: all n_src columns, n_q = n_src.  out_d2 may be NULL. */
+O3D_API int o3d_feature_nearest(o3d_ctx *ctx, const double *src_feature, int64_t n_src, const double *tgt_feature, int64_t n_tgt,
+                                int dim, const int32_t *query_ids, int64_t n_q, int mem, int32_t *out_index, double *out_d2);
+
+/* The per-iteration body of RegistrationRANSACBasedOnFeatureMatching between sampling and validation,
+ * Registration.cpp:250-268, for n_hyp candidate correspondence sets of ransac_n pairs each (corres: n_hyp x ransac_n x
+ * {source index, target index}): the checkers of CorrespondenceChecker.cpp:38-82 (edge_similarity, distance_threshold,
+ * normal_angle_threshold; a negative value leaves a checker out; the normal checker passes when either normals pointer is
+ * NULL, :67-72) and estimation.ComputeTransformation over the ransac_n pairs (TransformationEstimation.cpp:49-60,74-98).
+ * out_T: n_hyp x 16 column-major; out_ok[k] = 1 when every checker passed. */
+O3D_API int o3d_ransac_hypotheses(o3d_ctx *ctx, const double *src_xyz, const double *src_normals, int64_t n_src,
+                                  const double *tgt_xyz, const double *tgt_normals, int64_t n_tgt, const int32_t *corres,
+                                  int n_hyp, int ransac_n, int estimation, int with_scaling, double edge_similarity,
+                                  double distance_threshold, double normal_angle_threshold, int mem, double *out_T,
+                                  int32_t *out_ok);
+
+/* RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:199-301.  Sampling (utility::UniformRandInt, :234) runs on
+ * the host from std::mt19937(seed) (seed < 0: std::random_device, as the reference); feature matching, checkers,
+ * ComputeTransformation and the validation of :269-275 run on the device in batches, consumed in iteration order so
+ * that max_iteration / max_validation count as in the reference's serial loop.  Empty result (identity, fitness 0) for
+ * ransac_n < 3 or max_dist <= 0 (:207-209).  out_corr: per source point the matched target index or -1, for the returned
+ * transformation.  out_counts (nullable): {iterations run, validations run}. */
+O3D_API int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz, const double *src_normals, int64_t n_src,
+                                                     const double *tgt_xyz, const double *tgt_normals, int64_t n_tgt,
+                                                     const double *src_feature, const double *tgt_feature, int dim,
+                                                     double max_dist, int estimation, int with_scaling, int ransac_n,
+                                                     double edge_similarity, double distance_threshold,
+                                                     double normal_angle_threshold, int max_iteration, int max_validation,
+                                                     int64_t seed, int mem, double *out_T, int32_t *out_corr,
+                                                     int64_t *out_n_corr, double *out_fitness, double *out_rmse,
+                                                     int *out_counts);
+
 #ifdef __cplusplus
 }
 #endif

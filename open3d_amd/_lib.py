@@ -74,6 +74,16 @@ _SIGNATURES = {
     "o3d_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "o3d_compute_fpfh_feature": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int,
                                            C.c_void_p]),
+    "o3d_feature_nearest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                      C.c_int, C.c_void_p, C.c_void_p]),
+    "o3d_ransac_hypotheses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
+    "o3d_registration_ransac_feature_matching": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                           C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64,
+                                                           C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp,
+                                                           C.c_void_p]),
     "o3d_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "o3d_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <random>
 #include <thread>
 #include <vector>
 
@@ -154,6 +155,36 @@ struct o3d_ctx_full : o3d_ctx {
 };
 static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
 #define O3D_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock__(static_cast<o3d_ctx_full *>(ctx)->mu)
+
+// Device copies of caller buffers for the duration of one call (host memory: upload; device memory: used in place).
+namespace {
+struct DevBufs {
+  std::vector<void *> owned;
+  ~DevBufs() {
+    for (void *p : owned) (void)hipFree(p);
+  }
+  template <typename T>
+  int in(o3d_ctx *ctx, const T *p, size_t count, int mem, const T **out) {
+    *out = p;
+    if (!p || mem != O3D_MEM_HOST) return O3D_OK;
+    void *d = nullptr;
+    O3D_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+    owned.push_back(d);
+    if (count) O3D_HIP(ctx, hipMemcpyAsync(d, p, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    *out = (const T *)d;
+    return O3D_OK;
+  }
+  template <typename T>
+  int tmp(o3d_ctx *ctx, size_t count, T **out) {
+    void *d = nullptr;
+    O3D_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+    owned.push_back(d);
+    *out = (T *)d;
+    return O3D_OK;
+  }
+};
+}  // namespace
+
 
 extern "C" {
 
@@ -913,6 +944,259 @@ int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *norm
   O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_fpfh_impl(ctx, xyz, normals, n, search_type, knn, radius, mem, out_feature);
+}
+
+int o3d_feature_nearest(o3d_ctx *ctx, const double *src_feature, int64_t n_src, const double *tgt_feature, int64_t n_tgt, int dim,
+                        const int32_t *query_ids, int64_t n_q, int mem, int32_t *out_index, double *out_d2) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (n_src < 0 || n_tgt < 0 || n_q < 0 || dim < 1 || (n_src > 0 && !src_feature) || (n_tgt > 0 && !tgt_feature))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "o3d_feature_nearest: bad arguments");
+  if (!query_ids) n_q = n_src;
+  if (n_q == 0) return O3D_OK;
+  if (!out_index) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "o3d_feature_nearest: null output");
+  DeviceGuard guard(ctx->device);
+  ctx->icp_ready = 0;  // the scratch slots of the loop are reused
+  DevBufs b;
+  const double *d_sf, *d_tf;
+  const int32_t *d_q;
+  O3D_TRY(b.in(ctx, src_feature, (size_t)n_src * dim, mem, &d_sf));
+  O3D_TRY(b.in(ctx, tgt_feature, (size_t)n_tgt * dim, mem, &d_tf));
+  O3D_TRY(b.in(ctx, query_ids, (size_t)n_q, mem, &d_q));
+  int32_t *d_idx = out_index;
+  double *d_d2 = out_d2;
+  if (mem == O3D_MEM_HOST) {
+    O3D_TRY(b.tmp(ctx, (size_t)n_q, &d_idx));
+    if (out_d2) O3D_TRY(b.tmp(ctx, (size_t)n_q, &d_d2));
+  }
+  O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, d_q, n_q, d_idx, d_d2));
+  if (mem == O3D_MEM_HOST) {
+    O3D_HIP(ctx, hipMemcpyAsync(out_index, d_idx, sizeof(int32_t) * (size_t)n_q, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_d2) O3D_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, sizeof(double) * (size_t)n_q, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
+static void fill_ransac_args(RansacArgs &a, const double *d_src, const double *d_snrm, int64_t n_src, const double *d_tgt,
+                             const double *d_tnrm, int64_t n_tgt, int ransac_n, int estimation, int with_scaling,
+                             double edge_similarity, double distance_threshold, double normal_angle_threshold) {
+  a.src = d_src; a.snrm = d_snrm; a.tgt = d_tgt; a.tnrm = d_tnrm; a.n_src = n_src; a.n_tgt = n_tgt;
+  a.ransac_n = ransac_n; a.estimation = estimation; a.with_scaling = with_scaling;
+  a.use_edge = edge_similarity >= 0.0; a.use_dist = distance_threshold >= 0.0; a.use_normal = normal_angle_threshold >= 0.0;
+  a.edge_sim = edge_similarity; a.dist_thr = distance_threshold;
+  a.cos_normal = cos(normal_angle_threshold);  // CorrespondenceChecker.cpp:73
+}
+
+int o3d_ransac_hypotheses(o3d_ctx *ctx, const double *src_xyz, const double *src_normals, int64_t n_src, const double *tgt_xyz,
+                          const double *tgt_normals, int64_t n_tgt, const int32_t *corres, int n_hyp, int ransac_n, int estimation,
+                          int with_scaling, double edge_similarity, double distance_threshold, double normal_angle_threshold, int mem,
+                          double *out_T, int32_t *out_ok) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (n_hyp < 0 || ransac_n < 1 || n_src < 0 || n_tgt < 0 || (n_hyp > 0 && (!corres || !out_T || !out_ok)) ||
+      (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "o3d_ransac_hypotheses: bad arguments");
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "o3d_ransac_hypotheses: estimation type %d", estimation);
+  if (n_hyp == 0) return O3D_OK;
+  DeviceGuard guard(ctx->device);
+  DevBufs b;
+  const double *d_src, *d_snrm, *d_tgt, *d_tnrm;
+  const int32_t *d_c;
+  O3D_TRY(b.in(ctx, src_xyz, 3 * (size_t)n_src, mem, &d_src));
+  O3D_TRY(b.in(ctx, src_normals, 3 * (size_t)n_src, mem, &d_snrm));
+  O3D_TRY(b.in(ctx, tgt_xyz, 3 * (size_t)n_tgt, mem, &d_tgt));
+  O3D_TRY(b.in(ctx, tgt_normals, 3 * (size_t)n_tgt, mem, &d_tnrm));
+  O3D_TRY(b.in(ctx, corres, 2 * (size_t)ransac_n * (size_t)n_hyp, mem, &d_c));
+  double *d_T = out_T;
+  int32_t *d_ok = out_ok;
+  if (mem == O3D_MEM_HOST) {
+    O3D_TRY(b.tmp(ctx, 16 * (size_t)n_hyp, &d_T));
+    O3D_TRY(b.tmp(ctx, (size_t)n_hyp, &d_ok));
+  }
+  RansacArgs a;
+  fill_ransac_args(a, d_src, d_snrm, n_src, d_tgt, d_tnrm, n_tgt, ransac_n, estimation, with_scaling, edge_similarity,
+                   distance_threshold, normal_angle_threshold);
+  a.corres = d_c; a.n_hyp = n_hyp; a.out_T = d_T; a.out_ok = d_ok;
+  O3D_TRY(o3d_launch_ransac_hypotheses(ctx, a));
+  if (mem == O3D_MEM_HOST) {
+    O3D_HIP(ctx, hipMemcpyAsync(out_T, d_T, sizeof(double) * 16 * (size_t)n_hyp, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, sizeof(int32_t) * (size_t)n_hyp, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
+int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz, const double *src_normals, int64_t n_src,
+                                             const double *tgt_xyz, const double *tgt_normals, int64_t n_tgt,
+                                             const double *src_feature, const double *tgt_feature, int dim, double max_dist,
+                                             int estimation, int with_scaling, int ransac_n, double edge_similarity,
+                                             double distance_threshold, double normal_angle_threshold, int max_iteration,
+                                             int max_validation, int64_t seed, int mem, double *out_T, int32_t *out_corr,
+                                             int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_counts) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (n_src < 0 || n_tgt < 0 || dim < 1 || (n_src > 0 && (!src_xyz || !src_feature)) || (n_tgt > 0 && (!tgt_xyz || !tgt_feature)))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "RegistrationRANSACBasedOnFeatureMatching: bad arguments");
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "RegistrationRANSACBasedOnFeatureMatching: estimation type %d is not on the device path",
+                    estimation);
+  if (n_src >= ((int64_t)1 << 31) || n_tgt >= ((int64_t)1 << 31))
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "RegistrationRANSACBasedOnFeatureMatching: more than 2^31-1 points");
+  DeviceGuard guard(ctx->device);
+  static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double bestT[16];
+  memcpy(bestT, kIdentity, sizeof(bestT));
+  double bf = 0.0, br = 0.0;  // RegistrationResult(): fitness 0, rmse 0 (Registration.h:112-113)
+  int64_t bnc = 0;
+  int itr = 0, validations = 0;
+  bool have_best = false;
+  auto finish_empty = [&]() -> int {
+    if (out_T) memcpy(out_T, bestT, sizeof(bestT));
+    if (out_n_corr) *out_n_corr = 0;
+    if (out_fitness) *out_fitness = 0.0;
+    if (out_rmse) *out_rmse = 0.0;
+    if (out_counts) { out_counts[0] = itr; out_counts[1] = validations; }
+    if (out_corr && n_src > 0) {
+      if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        memset(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src);
+      }
+    }
+    return O3D_OK;
+  };
+  if (ransac_n < 3 || !(max_dist > 0.0) || n_src == 0 || n_tgt == 0 || max_iteration <= 0) return finish_empty();  // :207-209
+
+  DevBufs b;
+  const double *d_src, *d_snrm, *d_tgt, *d_tnrm, *d_sf, *d_tf;
+  O3D_TRY(b.in(ctx, src_xyz, 3 * (size_t)n_src, mem, &d_src));
+  O3D_TRY(b.in(ctx, src_normals, 3 * (size_t)n_src, mem, &d_snrm));
+  O3D_TRY(b.in(ctx, tgt_xyz, 3 * (size_t)n_tgt, mem, &d_tgt));
+  O3D_TRY(b.in(ctx, tgt_normals, 3 * (size_t)n_tgt, mem, &d_tnrm));
+  O3D_TRY(b.in(ctx, src_feature, (size_t)dim * (size_t)n_src, mem, &d_sf));
+  O3D_TRY(b.in(ctx, tgt_feature, (size_t)dim * (size_t)n_tgt, mem, &d_tf));
+
+  const int kBatch = 256;
+  // similar_features (:215, :235-242): the feature-space nearest neighbour of a source point, found when it is first
+  // sampled.  When the loop can sample most of the cloud anyway, all of them are found in one launch up front.
+  std::vector<int32_t> nn((size_t)n_src, -2);
+  int32_t *d_nn, *d_ids, *d_corres, *d_ok;
+  double *d_T;
+  const size_t max_ids = (size_t)kBatch * (size_t)ransac_n;
+  O3D_TRY(b.tmp(ctx, std::max<size_t>((size_t)n_src, max_ids), &d_nn));
+  O3D_TRY(b.tmp(ctx, max_ids, &d_ids));
+  O3D_TRY(b.tmp(ctx, 2 * max_ids, &d_corres));
+  O3D_TRY(b.tmp(ctx, (size_t)kBatch, &d_ok));
+  O3D_TRY(b.tmp(ctx, 16 * (size_t)kBatch, &d_T));
+  const bool all_up_front = (double)max_iteration * ransac_n >= 0.5 * (double)n_src;
+  if (all_up_front) {
+    O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, nullptr, n_src, d_nn, nullptr));
+    O3D_HIP(ctx, hipMemcpyAsync(nn.data(), d_nn, sizeof(int32_t) * (size_t)n_src, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+
+  // validation set-up: target grid, source in processing order with an untouched copy (as o3d_evaluate_hypotheses)
+  O3D_TRY(o3d_icp_setup(ctx, d_src, n_src, d_tgt, nullptr, n_tgt, max_dist, kIdentity, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0,
+                        O3D_MEM_DEVICE, n_src));
+  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->src_orig, &ctx->cap_src_orig, sizeof(double) * 3 * (size_t)n_src));
+  O3D_HIP(ctx, hipMemcpyAsync(ctx->src_orig, ctx->src_sorted, sizeof(double) * 3 * (size_t)n_src, hipMemcpyDeviceToDevice, ctx->stream));
+  void *d_all;
+  O3D_TRY(o3d_scratch(ctx, 7, sizeof(double) * O3D_NSUMS * (size_t)kBatch, &d_all));
+  ctx->hyp_mode = 1;
+
+  std::mt19937 rng;
+  if (seed < 0) {
+    std::random_device rd;  // utility/Helper.cpp:105-109
+    rng.seed(rd());
+  } else {
+    rng.seed((uint32_t)seed);
+  }
+  std::uniform_int_distribution<int> pick(0, (int)n_src - 1);
+  std::vector<int32_t> ids(max_ids), corres(2 * max_ids), ok(kBatch), pending;
+  std::vector<double> Ts(16 * (size_t)kBatch), sums((size_t)kBatch * O3D_NSUMS);
+  RansacArgs ra;
+  fill_ransac_args(ra, d_src, d_snrm, n_src, d_tgt, d_tnrm, n_tgt, ransac_n, estimation, with_scaling, edge_similarity,
+                   distance_threshold, normal_angle_threshold);
+  ra.corres = d_corres; ra.out_T = d_T; ra.out_ok = d_ok;
+
+  auto run = [&]() -> int {
+    while (itr < max_iteration && validations < max_validation) {
+      const int nb = std::min(kBatch, max_iteration - itr);
+      const size_t nid = (size_t)nb * (size_t)ransac_n;
+      for (size_t k = 0; k < nid; k++) ids[k] = pick(rng);  // :234
+      if (!all_up_front) {
+        pending.clear();
+        for (size_t k = 0; k < nid; k++)
+          if (nn[(size_t)ids[k]] == -2) { nn[(size_t)ids[k]] = -3; pending.push_back(ids[k]); }
+        if (!pending.empty()) {
+          O3D_HIP(ctx, hipMemcpyAsync(d_ids, pending.data(), sizeof(int32_t) * pending.size(), hipMemcpyHostToDevice, ctx->stream));
+          O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, d_ids, (int64_t)pending.size(), d_nn, nullptr));
+          std::vector<int32_t> got(pending.size());
+          O3D_HIP(ctx, hipMemcpyAsync(got.data(), d_nn, sizeof(int32_t) * pending.size(), hipMemcpyDeviceToHost, ctx->stream));
+          O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          for (size_t k = 0; k < pending.size(); k++) nn[(size_t)pending[k]] = got[k];
+        }
+      }
+      for (size_t k = 0; k < nid; k++) { corres[2 * k] = ids[k]; corres[2 * k + 1] = nn[(size_t)ids[k]]; }  // :243-245
+      O3D_HIP(ctx, hipMemcpyAsync(d_corres, corres.data(), sizeof(int32_t) * 2 * nid, hipMemcpyHostToDevice, ctx->stream));
+      ra.n_hyp = nb;
+      O3D_TRY(o3d_launch_ransac_hypotheses(ctx, ra));  // :250-268
+      O3D_HIP(ctx, hipMemcpyAsync(ok.data(), d_ok, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, hipMemcpyAsync(Ts.data(), d_T, sizeof(double) * 16 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      // validation (:269-284) of the hypotheses that passed, in iteration order, until max_validation is reached
+      int nv = 0;
+      std::vector<int> which;
+      for (int k = 0; k < nb && validations + nv < max_validation; k++) {
+        if (!ok[k]) continue;
+        O3D_TRY(o3d_launch_set_hypothesis(ctx, Ts.data() + 16 * (size_t)k));
+        O3D_TRY(o3d_icp_pass_to(ctx, (double *)d_all + (size_t)nv * O3D_NSUMS));
+        which.push_back(k);
+        nv++;
+      }
+      if (nv > 0) {
+        O3D_HIP(ctx, hipMemcpyAsync(sums.data(), d_all, sizeof(double) * (size_t)nv * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int v = 0; v < nv; v++) {
+          const double nc = sums[(size_t)v * O3D_NSUMS + O3D_SUM_NC];
+          const double fit = nc > 0.0 ? nc / (double)n_src : 0.0;
+          const double rm = nc > 0.0 ? sqrt(sums[(size_t)v * O3D_NSUMS + O3D_SUM_D2] / nc) : 0.0;
+          if (fit > bf || (fit == bf && rm < br)) {  // :272-275
+            bf = fit; br = rm; bnc = (int64_t)nc; have_best = true;
+            memcpy(bestT, Ts.data() + 16 * (size_t)which[v], sizeof(bestT));
+          }
+        }
+        validations += nv;
+      }
+      itr += nb;
+    }
+    if (out_T) memcpy(out_T, bestT, sizeof(bestT));
+    if (out_n_corr) *out_n_corr = bnc;
+    if (out_fitness) *out_fitness = bf;
+    if (out_rmse) *out_rmse = br;
+    if (out_counts) { out_counts[0] = itr; out_counts[1] = validations; }
+    if (out_corr) {
+      if (have_best) {  // the correspondence set of the kept result
+        O3D_TRY(o3d_launch_set_hypothesis(ctx, bestT));
+        O3D_TRY(o3d_icp_pass(ctx));
+        O3D_TRY(o3d_icp_fetch(ctx, mem, out_corr, nullptr, nullptr, nullptr));
+      } else if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src, ctx->stream));
+        O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        memset(out_corr, 0xFF, sizeof(int32_t) * (size_t)n_src);
+      }
+    }
+    return O3D_OK;
+  };
+  const int st = run();
+  ctx->hyp_mode = 0;
+  ctx->icp_ready = 0;
+  (void)hipStreamSynchronize(ctx->stream);  // nothing of this call may still read the buffers DevBufs frees
+  return st;
 }
 
 }  // extern "C"

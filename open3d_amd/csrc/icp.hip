@@ -1368,6 +1368,101 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, 
   out[18] = nc;
 }
 
+// RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:250-268, one lane per candidate correspondence set: the
+// checkers of CorrespondenceChecker.cpp:38-82 and estimation.ComputeTransformation over the ransac_n sampled pairs.
+__global__ __launch_bounds__(O3D_WAVE) void k_ransac_hypotheses(RansacArgs a) {
+  const int h = blockIdx.x * O3D_WAVE + threadIdx.x;
+  if (h >= a.n_hyp) return;
+  const int32_t *c = a.corres + 2 * (size_t)a.ransac_n * h;
+  double T[16];
+  mat4_identity(T);
+  int ok = 1;
+  for (int j = 0; j < a.ransac_n; j++)
+    if (c[2 * j] < 0 || c[2 * j] >= a.n_src || c[2 * j + 1] < 0 || c[2 * j + 1] >= a.n_tgt) ok = 0;
+  if (ok && a.use_edge) {  // CorrespondenceCheckerBasedOnEdgeLength::Check, :38-51
+    for (int i = 0; i < a.ransac_n && ok; i++)
+      for (int j = i + 1; j < a.ransac_n; j++) {
+        const double *si = a.src + 3 * (size_t)c[2 * i], *sj = a.src + 3 * (size_t)c[2 * j];
+        const double *ti = a.tgt + 3 * (size_t)c[2 * i + 1], *tj = a.tgt + 3 * (size_t)c[2 * j + 1];
+        const double sx = si[0] - sj[0], sy = si[1] - sj[1], sz = si[2] - sj[2];
+        const double tx = ti[0] - tj[0], ty = ti[1] - tj[1], tz = ti[2] - tj[2];
+        const double ds = sqrt((sx * sx + sy * sy) + sz * sz), dt = sqrt((tx * tx + ty * ty) + tz * tz);
+        if (ds < dt * a.edge_sim || dt < ds * a.edge_sim) { ok = 0; break; }
+      }
+  }
+  if (ok) {  // ComputeTransformation over the sampled pairs (an identity for point-to-plane without target normals, :76-77)
+    const double *t0 = a.tgt + 3 * (size_t)c[1];
+    const double c0[3] = {t0[0], t0[1], t0[2]};
+    double acc[30];
+    for (int k = 0; k < 30; k++) acc[k] = 0.0;
+    const bool plane = a.estimation == O3D_EST_POINT_TO_PLANE;
+    for (int j = 0; j < a.ransac_n; j++) {
+      const double *sp = a.src + 3 * (size_t)c[2 * j], *tp = a.tgt + 3 * (size_t)c[2 * j + 1];
+      const double4 p = make_double4(tp[0], tp[1], tp[2], 0.0);
+      Best b;
+      const double dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
+      double d2 = dx * dx;
+      d2 = d2 + dy * dy;
+      d2 = d2 + dz * dz;
+      b.d2 = d2; b.idx = c[2 * j + 1]; b.pos = 0;
+      if (plane) {
+        if (a.tnrm) {
+          const double *np = a.tnrm + 3 * (size_t)c[2 * j + 1];
+          accumulate<O3D_EST_POINT_TO_PLANE>(acc, sp[0], sp[1], sp[2], b, p, np[0], np[1], np[2], c0[0], c0[1], c0[2]);
+        }
+      } else {
+        accumulate<O3D_EST_POINT_TO_POINT>(acc, sp[0], sp[1], sp[2], b, p, 0.0, 0.0, 0.0, c0[0], c0[1], c0[2]);
+      }
+    }
+    double q[O3D_NSUMS];
+    for (int k = 0; k < 30; k++) q[k] = acc[k];
+    q[30] = q[31] = 0.0;
+    if (q[O3D_SUM_NC] > 0.0) {
+      if (plane) {
+        double A[36], bb[6], x[6];
+        SolveWork wk;
+        int k = 0;
+        for (int r = 0; r < 6; r++)
+          for (int cc = r; cc < 6; cc++) { A[r * 6 + cc] = q[k]; A[cc * 6 + r] = q[k]; k++; }
+        for (int r = 0; r < 6; r++) bb[r] = -q[21 + r];
+        ldlt_solve6(A, bb, x, wk);
+        vec6_to_mat4(x, T);
+      } else {
+        umeyama_from_sums(q, c0, a.with_scaling, T);
+      }
+    }
+  }
+  if (ok && a.use_dist) {  // CorrespondenceCheckerBasedOnDistance::Check, :53-63
+    for (int j = 0; j < a.ransac_n; j++) {
+      const double *sp = a.src + 3 * (size_t)c[2 * j], *tp = a.tgt + 3 * (size_t)c[2 * j + 1];
+      double d[3];
+      for (int r = 0; r < 3; r++) {
+        double v = TM(T, r, 0) * sp[0];
+        v = v + TM(T, r, 1) * sp[1];
+        v = v + TM(T, r, 2) * sp[2];
+        v = v + TM(T, r, 3);
+        d[r] = tp[r] - v;
+      }
+      if (sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) > a.dist_thr) { ok = 0; break; }
+    }
+  }
+  if (ok && a.use_normal && a.snrm && a.tnrm) {  // CorrespondenceCheckerBasedOnNormal::Check, :65-82
+    for (int j = 0; j < a.ransac_n; j++) {
+      const double *sn = a.snrm + 3 * (size_t)c[2 * j], *tn = a.tnrm + 3 * (size_t)c[2 * j + 1];
+      double dot = 0.0;
+      for (int r = 0; r < 3; r++) {
+        double v = TM(T, r, 0) * sn[0];
+        v = v + TM(T, r, 1) * sn[1];
+        v = v + TM(T, r, 2) * sn[2];
+        dot = (r == 0) ? tn[0] * v : dot + tn[r] * v;
+      }
+      if (dot < a.cos_normal) { ok = 0; break; }
+    }
+  }
+  for (int i = 0; i < 16; i++) a.out_T[16 * (size_t)h + i] = T[i];
+  a.out_ok[h] = ok;
+}
+
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_tcol(const double4 *__restrict__ tgt_sorted, const double *__restrict__ col,
                                                             const double *__restrict__ grad, int64_t n, double4 *__restrict__ out) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -1441,6 +1536,13 @@ int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const dou
   else
     hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_POINT>, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, a);
   hipLaunchKernelGGL(k_pairs_estimate, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, a, (int)g, estimation, with_scaling, dev_out);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_launch_ransac_hypotheses(o3d_ctx *ctx, const RansacArgs &a) {
+  if (a.n_hyp <= 0) return O3D_OK;
+  hipLaunchKernelGGL(k_ransac_hypotheses, dim3((a.n_hyp + O3D_WAVE - 1) / O3D_WAVE), dim3(O3D_WAVE), 0, ctx->stream, a);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

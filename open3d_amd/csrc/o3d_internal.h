@@ -153,6 +153,21 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
 // AABB over finite points: out6 (host) = {minx,miny,minz,maxx,maxy,maxz}; *out_finite = number of finite points.
 int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], int64_t *out_finite);
 
+// ---- RANSAC (icp.hip: hypotheses; ransac.hip: feature matching and the driver) ---
+struct RansacArgs {
+  const double *src, *snrm, *tgt, *tnrm;  // caller's order, 3 doubles per point; normals nullable
+  int64_t n_src, n_tgt;
+  const int32_t *corres;  // n_hyp x ransac_n x {source index, target index}
+  int n_hyp, ransac_n, estimation, with_scaling;
+  int use_edge, use_dist, use_normal;
+  double edge_sim, dist_thr, cos_normal;
+  double *out_T;      // n_hyp x 16, column-major
+  int32_t *out_ok;    // n_hyp
+};
+int o3d_launch_ransac_hypotheses(o3d_ctx *ctx, const RansacArgs &a);
+int o3d_feature_nn_device(o3d_ctx *ctx, const double *d_src_feat, int64_t n_src, const double *d_tgt_feat, int64_t n_tgt, int dim,
+                          const int32_t *d_query_ids, int64_t n_q, int32_t *d_out_index, double *d_out_d2);
+
 // ---- device helpers -------------------------------------------------------------
 __device__ __forceinline__ int o3d_cell_coord(double x, double gmin, double inv_h, int n) {
   // monotone in x; NaN -> -2 (no neighbours); clamped to [-2, n+1]

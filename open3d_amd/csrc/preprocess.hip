@@ -222,6 +222,7 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 }
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
+constexpr int kNrmLoads = 8;   // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
 constexpr int kMaxKnn = 128;  // 16 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel.
@@ -359,19 +360,19 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
             xa = max(xa, -1); xb = min(xb, gp.nx);
             if (xa > xb) continue;
             const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-            for (uint32_t j0 = s; j0 < e; j0 += 4) {  // four candidate loads in flight; processed in run order
-              double4 tq[4];
+            for (uint32_t j0 = s; j0 < e; j0 += kNrmLoads) {  // candidate loads in flight; processed in run order
+              double4 tq[kNrmLoads];
 #pragma unroll
-              for (int u = 0; u < 4; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
+              for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
+              for (int u = 0; u < kNrmLoads; u++) {
                 const uint32_t j = j0 + (uint32_t)u;
-                if (j >= e) break;
                 const double4 t = tq[u];
                 const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
                 double d2 = ddx * ddx;
                 d2 = d2 + ddy * ddy;
                 d2 = d2 + ddz * ddz;
+                if (j >= e) d2 = INFINITY;  // past the end of the run: rejected by every mode below
                 if (MODE == 1) {
                   if (d2 < thr) {
                     count++;

@@ -271,6 +271,130 @@ def ComputeFPFHFeature(input, search_param=None, ctx=None):
     return Feature(out[: len(pts)].T)  # a 33 x n view of the column-major storage
 
 
+class RANSACConvergenceCriteria:
+    """Registration.h:87-102."""
+
+    def __init__(self, max_iteration=1000, max_validation=1000):
+        self.max_iteration_ = int(max_iteration)
+        self.max_validation_ = int(max_validation)
+
+
+class CorrespondenceCheckerBasedOnEdgeLength:
+    """CorrespondenceChecker.h / .cpp:38-51."""
+    require_pointcloud_alignment_ = False
+
+    def __init__(self, similarity_threshold=0.9):
+        self.similarity_threshold_ = float(similarity_threshold)
+
+
+class CorrespondenceCheckerBasedOnDistance:
+    """CorrespondenceChecker.cpp:53-63."""
+    require_pointcloud_alignment_ = True
+
+    def __init__(self, distance_threshold):
+        self.distance_threshold_ = float(distance_threshold)
+
+
+class CorrespondenceCheckerBasedOnNormal:
+    """CorrespondenceChecker.cpp:65-82."""
+    require_pointcloud_alignment_ = True
+
+    def __init__(self, normal_angle_threshold):
+        self.normal_angle_threshold_ = float(normal_angle_threshold)
+
+
+def _checker_thresholds(checkers):
+    """The device path runs the reference's three checkers; several of one kind combine into the strictest one (they
+    are ANDed in Registration.cpp:251-266)."""
+    edge, dist, ang = -1.0, -1.0, -1.0
+    for c in checkers or []:
+        if isinstance(c, CorrespondenceCheckerBasedOnEdgeLength):
+            edge = max(edge, c.similarity_threshold_)
+        elif isinstance(c, CorrespondenceCheckerBasedOnDistance):
+            dist = c.distance_threshold_ if dist < 0 else min(dist, c.distance_threshold_)
+        elif isinstance(c, CorrespondenceCheckerBasedOnNormal):
+            ang = c.normal_angle_threshold_ if ang < 0 else min(ang, c.normal_angle_threshold_)
+        else:
+            raise _lib.O3DError(5, "a user-defined CorrespondenceChecker has no device path")
+    return edge, dist, ang
+
+
+def _feat(f):
+    """Feature (dim x n) -> the column-major storage of Feature::data_: n rows of dim doubles."""
+    d = f.data_ if isinstance(f, Feature) else np.asarray(f)
+    return np.ascontiguousarray(np.asarray(d, dtype=np.float64).T)
+
+
+def FeatureNearest(source_feature, target_feature, query_ids=None, ctx=None):
+    """The feature matching of RegistrationRANSACBasedOnFeatureMatching (Registration.cpp:223,237): for each queried source
+    column the nearest target column (KDTreeFlann::SearchKNN(.., 1)).  Returns (index int32[n_q], squared distance[n_q])."""
+    ctx = ctx or _lib.default_context()
+    sf, tf = _feat(source_feature), _feat(target_feature)
+    q = None if query_ids is None else np.ascontiguousarray(query_ids, np.int32)
+    nq = len(sf) if q is None else len(q)
+    idx = np.full(max(nq, 1), -1, np.int32)
+    d2 = np.zeros(max(nq, 1))
+    ctx.check(ctx._lib.o3d_feature_nearest(ctx.handle, _lib.ptr(sf), len(sf), _lib.ptr(tf), len(tf), sf.shape[1], _lib.ptr(q), nq,
+                                           _lib.MEM_HOST, _lib.ptr(idx), _lib.ptr(d2)))
+    return idx[:nq], d2[:nq]
+
+
+def RansacHypotheses(source, target, corres, estimation=None, checkers=None, ctx=None):
+    """Registration.cpp:250-268 for a batch of candidate correspondence sets (n_hyp x ransac_n x 2): checkers and
+    estimation.ComputeTransformation.  Returns (T[n_hyp, 4, 4], ok[n_hyp] bool)."""
+    ctx = ctx or _lib.default_context()
+    estimation = estimation or TransformationEstimationPointToPoint(False)
+    c = np.ascontiguousarray(corres, np.int32)
+    assert c.ndim == 3 and c.shape[2] == 2
+    n_hyp, ransac_n = c.shape[0], c.shape[1]
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    snrm = np.ascontiguousarray(source.normals_, dtype=np.float64) if source.HasNormals() else None
+    tnrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    edge, dist, ang = _checker_thresholds(checkers)
+    T = np.zeros((max(n_hyp, 1), 16))
+    ok = np.zeros(max(n_hyp, 1), np.int32)
+    ctx.check(ctx._lib.o3d_ransac_hypotheses(
+        ctx.handle, _lib.ptr(src), _lib.ptr(snrm), len(src), _lib.ptr(tgt), _lib.ptr(tnrm), len(tgt), _lib.ptr(c), n_hyp, ransac_n,
+        estimation.GetTransformationEstimationType(), int(getattr(estimation, "with_scaling_", False)), edge, dist, ang,
+        _lib.MEM_HOST, _lib.ptr(T), _lib.ptr(ok)))
+    return np.stack([_lib.from_colmajor(T[k]) for k in range(n_hyp)]) if n_hyp else np.zeros((0, 4, 4)), ok[:n_hyp].astype(bool)
+
+
+def RegistrationRANSACBasedOnFeatureMatching(source, target, source_feature, target_feature, max_correspondence_distance,
+                                             estimation=None, ransac_n=4, checkers=None, criteria=None, seed=-1, ctx=None):
+    """RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:199-301.  seed < 0: std::random_device like the
+    reference (not reproducible); seed >= 0: std::mt19937(seed)."""
+    ctx = ctx or _lib.default_context()
+    estimation = estimation or TransformationEstimationPointToPoint(False)
+    criteria = criteria or RANSACConvergenceCriteria()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    snrm = np.ascontiguousarray(source.normals_, dtype=np.float64) if source.HasNormals() else None
+    tnrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    sf, tf = _feat(source_feature), _feat(target_feature)
+    if len(sf) != len(src) or len(tf) != len(tgt) or sf.shape[1] != tf.shape[1]:
+        raise _lib.O3DError(1, "feature and point counts / dimensions do not match")
+    edge, dist, ang = _checker_thresholds(checkers)
+    T = np.zeros(16)
+    corr = np.empty(max(len(src), 1), np.int32)
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    counts = np.zeros(2, np.int32)
+    ctx.check(ctx._lib.o3d_registration_ransac_feature_matching(
+        ctx.handle, _lib.ptr(src), _lib.ptr(snrm), len(src), _lib.ptr(tgt), _lib.ptr(tnrm), len(tgt), _lib.ptr(sf), _lib.ptr(tf),
+        sf.shape[1], float(max_correspondence_distance), estimation.GetTransformationEstimationType(),
+        int(getattr(estimation, "with_scaling_", False)), int(ransac_n), edge, dist, ang, criteria.max_iteration_,
+        criteria.max_validation_, int(seed), _lib.MEM_HOST, T.ctypes.data_as(_lib.c_dp), _lib.ptr(corr), C.byref(nc), C.byref(fit),
+        C.byref(rmse), _lib.ptr(counts)))
+    res = RegistrationResult(_lib.from_colmajor(T))
+    res.corr_ = corr[: len(src)].copy()
+    res.correspondence_set_ = _pairs(res.corr_)
+    res.fitness_, res.inlier_rmse_, res.n_corr_ = fit.value, rmse.value, nc.value
+    res.iterations_, res.validations_ = int(counts[0]), int(counts[1])
+    return res
+
+
 def EvaluateHypotheses(source, target, max_correspondence_distance, transformations, want_corr=True, ctx=None):
     """The validation step of RegistrationRANSACBasedOnFeatureMatching (Registration.cpp:269-275) for a list of candidate
     transformations.  Returns (fitness[k], inlier_rmse[k], best RegistrationResult or None): `best` is the hypothesis

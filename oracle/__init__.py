@@ -283,6 +283,30 @@ def neighbor_query(mode, cloud, queries, knn=1, radius=0.0):
     return cnt[: len(queries)] if mode == 2 else out
 
 
+def feature_nearest(src_feat, tgt_feat, query_ids=None):
+    """Registration.cpp:223,237: nearest target column (flann::L2<double>, ties -> lowest index) of the queried source
+    columns.  Features are dim x n (Feature::data_).  Returns (index int32[n_q], d2[n_q])."""
+    sf = np.ascontiguousarray(np.asarray(src_feat, np.float64).T)
+    tf = np.ascontiguousarray(np.asarray(tgt_feat, np.float64).T)
+    q = None if query_ids is None else np.ascontiguousarray(query_ids, np.int32)
+    nq = len(sf) if q is None else len(q)
+    idx = np.full(max(nq, 1), -1, np.int32)
+    d2 = np.zeros(max(nq, 1))
+    lib().orc_feature_nearest(_d(sf), C.c_int64(len(sf)), _d(tf), C.c_int64(len(tf)), int(sf.shape[1]) if sf.ndim == 2 else 0,
+                              _i(q) if q is not None else None, C.c_int64(nq), _i(idx), _d(d2))
+    return idx[:nq], d2[:nq]
+
+
+def ransac_check(src, tgt, corres, T, edge_sim=-1.0, dist_thr=-1.0, normal_angle=-1.0, src_normals=None, tgt_normals=None):
+    """CorrespondenceChecker.cpp:38-82 on one correspondence set (n x 2 {source, target})."""
+    c = np.ascontiguousarray(corres, np.int32)
+    f = lib().orc_ransac_check
+    f.restype = C.c_int
+    return bool(f(_d(_pts(src)), _d(_pts(src_normals)) if src_normals is not None else None, _d(_pts(tgt)),
+                  _d(_pts(tgt_normals)) if tgt_normals is not None else None, _i(c), len(c), _d(_mat(T)), C.c_double(edge_sim),
+                  C.c_double(dist_thr), C.c_double(normal_angle)))
+
+
 def voxel_down_sample(pts, voxel, normals=None, colors=None):
     """PointCloud.cpp:273-306 -> (points, normals|None, colors|None, voxel_index int32[M,3]); sorted by (z,y,x)."""
     pts = _pts(pts)

@@ -1475,3 +1475,74 @@ ORC_EXPORT int orc_neighbors(const double *pts, int64_t n, const double *q, int 
   orc_kdtree_free(kd);
   return k;
 }
+
+/* ---- RegistrationRANSACBasedOnFeatureMatching pieces (Registration.cpp:199-301) ------------------------------------
+ * Feature-space nearest neighbour, Registration.cpp:223,237: KDTreeFlann over the target Feature, SearchKNN(column, 1)
+ * (KDTreeFlann.cpp:93-110).  The KD-tree search is exact, so the result is the argmin of flann::L2<double> -- restated
+ * here as an exhaustive scan with L2's own summation order (groups of four, then the tail) and ties to the
+ * lowest index (the north-star rule; FLANN keeps the first visited). */
+static double orc_flann_l2(const double *a, const double *b, int dim) {
+  double result = 0.0;
+  int k = 0;
+  for (; k + 3 < dim; k += 4) {
+    const double d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2], d3 = a[k + 3] - b[k + 3];
+    result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  for (; k < dim; k++) {
+    const double d = a[k] - b[k];
+    result += d * d;
+  }
+  return result;
+}
+
+ORC_EXPORT void orc_feature_nearest(const double *sf, int64_t n_src, const double *tf, int64_t n_tgt, int dim, const int32_t *qids,
+                                    int64_t n_q, int32_t *out_idx, double *out_d2) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int64_t q = 0; q < n_q; q++) {
+    const int64_t id = qids ? qids[q] : q;
+    int32_t bi = -1;
+    double bd = 0.0;
+    if (id >= 0 && id < n_src)
+      for (int64_t t = 0; t < n_tgt; t++) {
+        const double d = orc_flann_l2(sf + (size_t)id * dim, tf + (size_t)t * dim, dim);
+        if (bi < 0 ? d < INFINITY : d < bd) { bd = d; bi = (int32_t)t; }
+      }
+    out_idx[q] = bi;
+    if (out_d2) out_d2[q] = bd;
+  }
+}
+
+/* The checkers of CorrespondenceChecker.cpp:38-82 on one correspondence set of n pairs {source index, target index}.
+ * T column-major.  A negative threshold leaves a checker out; the normal checker passes without normals (:67-72). */
+ORC_EXPORT int orc_ransac_check(const double *src, const double *snrm, const double *tgt, const double *tnrm, const int32_t *c, int n,
+                                const double *T, double edge_sim, double dist_thr, double normal_angle) {
+  if (edge_sim >= 0.0)
+    for (int i = 0; i < n; i++)
+      for (int j = i + 1; j < n; j++) {
+        const double *si = src + 3 * (size_t)c[2 * i], *sj = src + 3 * (size_t)c[2 * j];
+        const double *ti = tgt + 3 * (size_t)c[2 * i + 1], *tj = tgt + 3 * (size_t)c[2 * j + 1];
+        const double sx = si[0] - sj[0], sy = si[1] - sj[1], sz = si[2] - sj[2];
+        const double tx = ti[0] - tj[0], ty = ti[1] - tj[1], tz = ti[2] - tj[2];
+        const double ds = sqrt((sx * sx + sy * sy) + sz * sz), dt = sqrt((tx * tx + ty * ty) + tz * tz);
+        if (ds < dt * edge_sim || dt < ds * edge_sim) return 0;
+      }
+  if (dist_thr >= 0.0)
+    for (int j = 0; j < n; j++) {
+      const double *sp = src + 3 * (size_t)c[2 * j], *tp = tgt + 3 * (size_t)c[2 * j + 1];
+      double d[3];
+      for (int r = 0; r < 3; r++) d[r] = tp[r] - (((T[r] * sp[0] + T[4 + r] * sp[1]) + T[8 + r] * sp[2]) + T[12 + r]);
+      if (sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) > dist_thr) return 0;
+    }
+  if (normal_angle >= 0.0 && snrm && tnrm) {
+    const double ct = cos(normal_angle);
+    for (int j = 0; j < n; j++) {
+      const double *sn = snrm + 3 * (size_t)c[2 * j], *tn = tnrm + 3 * (size_t)c[2 * j + 1];
+      double v[3];
+      for (int r = 0; r < 3; r++) v[r] = (T[r] * sn[0] + T[4 + r] * sn[1]) + T[8 + r] * sn[2];
+      if ((tn[0] * v[0] + tn[1] * v[1]) + tn[2] * v[2] < ct) return 0;
+    }
+  }
+  return 1;
+}
