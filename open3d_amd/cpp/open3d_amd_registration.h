@@ -552,6 +552,53 @@ inline std::vector<double> ComputeFPFHFeatureData(const o3d_types::PointCloud &i
   return data;
 }
 
+// RANSACConvergenceCriteria, Registration.h:87-102
+class RANSACConvergenceCriteria {
+ public:
+  RANSACConvergenceCriteria(int max_iteration = 1000, int max_validation = 1000)
+      : max_iteration_(max_iteration), max_validation_(max_validation) {}
+  int max_iteration_;
+  int max_validation_;
+};
+
+// The three checkers of CorrespondenceChecker.h; their Check() bodies (CorrespondenceChecker.cpp:38-82) run on the device
+// inside o3d_ransac_hypotheses, so the stand-ins only carry the thresholds.  A negative threshold = checker absent.
+struct CorrespondenceCheckers {
+  double edge_length_similarity_ = -1.0;    // CorrespondenceCheckerBasedOnEdgeLength::similarity_threshold_
+  double distance_threshold_ = -1.0;        // CorrespondenceCheckerBasedOnDistance::distance_threshold_
+  double normal_angle_threshold_ = -1.0;    // CorrespondenceCheckerBasedOnNormal::normal_angle_threshold_
+};
+
+// RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:199-301.  Features are the storage of Feature::data_
+// (dim x n, column-major: source_feature.data_.data()).  seed < 0: std::random_device, as the reference.
+inline RegistrationResult RegistrationRANSACBasedOnFeatureMatching(
+    const o3d_types::PointCloud &source, const o3d_types::PointCloud &target, const double *source_feature,
+    const double *target_feature, int feature_dim, double max_correspondence_distance,
+    const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false), int ransac_n = 4,
+    const CorrespondenceCheckers &checkers = CorrespondenceCheckers(),
+    const RANSACConvergenceCriteria &criteria = RANSACConvergenceCriteria(), int64_t seed = -1, Context &c = Context::Default()) {
+  if (!IsAccelerated(estimation))
+    throw std::runtime_error("open3d_amd: RegistrationRANSACBasedOnFeatureMatching needs a point-to-point or point-to-plane estimation");
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  int with_scaling = 0;
+  if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
+  RegistrationResult result;
+  std::vector<int32_t> corr(source.points_.size());
+  int64_t nc = 0;
+  double T[16];
+  Check(c.get(), o3d_registration_ransac_feature_matching(
+                     c.get(), (const double *)source.points_.data(), source.HasNormals() ? (const double *)source.normals_.data() : nullptr,
+                     (int64_t)source.points_.size(), (const double *)target.points_.data(),
+                     target.HasNormals() ? (const double *)target.normals_.data() : nullptr, (int64_t)target.points_.size(),
+                     source_feature, target_feature, feature_dim, max_correspondence_distance,
+                     p2l ? O3D_EST_POINT_TO_PLANE : O3D_EST_POINT_TO_POINT, with_scaling, ransac_n, checkers.edge_length_similarity_,
+                     checkers.distance_threshold_, checkers.normal_angle_threshold_, criteria.max_iteration_, criteria.max_validation_,
+                     seed, O3D_MEM_HOST, T, corr.data(), &nc, &result.fitness_, &result.inlier_rmse_, nullptr));
+  for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
+  detail::ExpandCorrespondences(corr, result.correspondence_set_);
+  return result;
+}
+
 // GetInformationMatrixFromPointClouds, Registration.cpp:303-355
 inline o3d_types::Mat6 GetInformationMatrixFromPointClouds(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                                            double max_correspondence_distance,

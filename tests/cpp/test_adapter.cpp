@@ -122,6 +122,24 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 16; i++) put(out, cr.transformation_.m[i]);
   put(out, cr.fitness_); put(out, cr.inlier_rmse_);
 
+  // global registration: FPFH on both clouds, RANSAC with a fixed seed (the Python side repeats the run)
+  geometry::PointCloud gs = source, gt = target;
+  gs.EstimateNormals(geometry::KDTreeSearchParamHybrid(2.0 * radius, 30));
+  gt.EstimateNormals(geometry::KDTreeSearchParamHybrid(2.0 * radius, 30));
+  for (auto *pc : {&gs, &gt})   // one orientation for both clouds (the height field faces +z)
+    for (auto &nv : pc->normals_)
+      if (nv(2) < 0.0) nv = Vector3d(-nv(0), -nv(1), -nv(2));
+  std::vector<double> fs = reg::ComputeFPFHFeatureData(gs, geometry::KDTreeSearchParamHybrid(5.0 * radius, 100));
+  std::vector<double> ft = reg::ComputeFPFHFeatureData(gt, geometry::KDTreeSearchParamHybrid(5.0 * radius, 100));
+  reg::CorrespondenceCheckers chk;
+  chk.edge_length_similarity_ = 0.9;
+  chk.distance_threshold_ = 1.5 * radius;
+  reg::RegistrationResult gr = reg::RegistrationRANSACBasedOnFeatureMatching(
+      gs, gt, fs.data(), ft.data(), 33, 1.5 * radius, reg::TransformationEstimationPointToPoint(false), 4, chk,
+      reg::RANSACConvergenceCriteria(20000, 500), 5);
+  for (int i = 0; i < 16; i++) put(out, gr.transformation_.m[i]);
+  put(out, gr.fitness_); put(out, gr.inlier_rmse_); put(out, (double)gr.correspondence_set_.size());
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(out.data(), 8, out.size(), f);

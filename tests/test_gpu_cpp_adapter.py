@@ -80,4 +80,20 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
     assert rel_err(out[o:o + 16].reshape(4, 4).T, cw.transformation_) < 1e-6
     assert rel_err(out[o + 16], cw.fitness_) < 1e-6 and rel_err(out[o + 17], cw.inlier_rmse_) < 1e-6
     o += 18
+    gs, gt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm.copy())
+    gs.EstimateNormals(geometry.KDTreeSearchParamHybrid(2.0 * radius, 30), ctx=ctx)
+    gt.EstimateNormals(geometry.KDTreeSearchParamHybrid(2.0 * radius, 30), ctx=ctx)
+    for pc in (gs, gt):
+        pc.normals_[pc.normals_[:, 2] < 0] *= -1.0
+    fs = reg.ComputeFPFHFeature(gs, geometry.KDTreeSearchParamHybrid(5.0 * radius, 100), ctx=ctx)
+    ft = reg.ComputeFPFHFeature(gt, geometry.KDTreeSearchParamHybrid(5.0 * radius, 100), ctx=ctx)
+    gw = reg.RegistrationRANSACBasedOnFeatureMatching(
+        gs, gt, fs, ft, 1.5 * radius, reg.TransformationEstimationPointToPoint(False), 4,
+        [reg.CorrespondenceCheckerBasedOnEdgeLength(0.9), reg.CorrespondenceCheckerBasedOnDistance(1.5 * radius)],
+        reg.RANSACConvergenceCriteria(20000, 500), seed=5, ctx=ctx)
+    # same seed, same device code: the same run
+    assert np.array_equal(out[o:o + 16].reshape(4, 4).T, gw.transformation_)
+    assert out[o + 16] == gw.fitness_ and out[o + 17] == gw.inlier_rmse_ and int(out[o + 18]) == len(gw.correspondence_set_)
+    assert gw.fitness_ > 0.5
+    o += 19
     assert o == len(out)
