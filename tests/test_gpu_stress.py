@@ -1,6 +1,7 @@
 """Stress cases for the pruned cell search: queries hugging cell faces, large coordinate offsets, clustered targets."""
 import numpy as np
 import pytest
+from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +132,42 @@ def test_bench_exchange_path_under_torchrun_one_rank():
     assert ja["n_gpus"] == 1 and ja["value"] > 0
     for k in ("fitness", "inlier_rmse", "n_corr"):
         assert ja["config"][k] == pytest.approx(jb["config"][k], rel=1e-12), k
+
+
+def test_seeded_search_walk_on_lattice_with_ties(ctx, oracle):
+    """The previous pass's match seeds the next search (k_icp_search_coop).  A walk of caller-given updates over a lattice
+    target -- exact ties between 2, 4 and 8 targets, matches that move to another cell, jumps that make the seed useless,
+    queries that lose and regain their match -- must give the oracle's correspondences after every single pass."""
+    from open3d_amd.pipelines import registration as reg
+    g = np.arange(24, dtype=np.float64)
+    X, Y, Z = np.meshgrid(g, g, np.arange(3, dtype=np.float64), indexing="ij")
+    tgt = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+    rng = np.random.default_rng(12)
+    base = rng.integers(2, 20, (6000, 3)).astype(np.float64)
+    base[:, 2] = rng.integers(0, 3, 6000)
+    off = np.array([[0.5, 0, 0], [0.5, 0.5, 0], [0.5, 0.5, 0.5], [0.25, 0, 0], [0, 0, 0], [0.5, 0.25, 0.125]])
+    src = base + off[rng.integers(0, len(off), 6000)]
+    r = 1.0
+
+    def shift(x, y, z):
+        T = np.eye(4)
+        T[:3, 3] = (x, y, z)
+        return T
+
+    walk = [np.eye(4), shift(1, 0, 0), shift(0, -1, 0), shift(0.25, 0, 0), shift(-0.25, 0.5, 0), shift(0, 0, 0.5),
+            shift(7, 3, 0), shift(-7, -3, -0.5), shift(0, 0, 40.0), shift(0, 0, -40.0), shift(0.5, 0.5, 0.5), shift(-1.5, -0.5, -0.5)]
+    for use_tile in (True, False):
+        ctx.debug_set(use_tile_search=use_tile)
+        sess = reg.IcpSession(ctx).setup(src, tgt, None, r, np.eye(4), reg.TransformationEstimationPointToPoint(),
+                                         reg.ICPConvergenceCriteria(0, 0, 100))
+        cur = src.copy()
+        for k, U in enumerate(walk):
+            if k > 0:
+                sess.set_update(U)
+                cur = oracle.transform_points(U, cur)
+            sess.enqueue_pass()
+            got = sess.fetch()
+            corr, nc, sd2, fit, rmse = oracle.correspondences(cur, tgt, r)
+            assert np.array_equal(got.corr_, corr), "pass %d (tile search %s)" % (k, use_tile)
+            assert got.fitness_ == fit and rel_err(got.inlier_rmse_, rmse) < 1e-12 if nc else got.fitness_ == 0.0
+    ctx.debug_set(use_tile_search=True)
