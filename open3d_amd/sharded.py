@@ -96,3 +96,66 @@ class ShardedICP:
 
     def finish(self, want_corr=True):
         return self.engine.finish(want_corr=want_corr)
+
+
+def pair_indices(n_pairs, world_size, rank):
+    """Pairs of a batch dealt round-robin: rank g registers pairs g, g + G, g + 2G, ... (BASELINE config 5)."""
+    return list(range(rank, n_pairs, world_size))
+
+
+class ShardedBatch:
+    """Batches of independent fragment pairs over a process group: no data-path collective.
+
+    Every rank registers its own pairs on its own GPU (RegistrationICPBatch by default); only the results -- 19 doubles
+    per pair: transformation, fitness, inlier_rmse, iterations -- are gathered at the end so that every rank can return
+    the whole list in pair order.  `run_local(indices) -> [RegistrationResult]` is injectable for the CPU tests."""
+
+    ROW = 19
+
+    def __init__(self, run_local, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.run_local = run_local
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device if device is not None else torch.device("cpu")
+
+    def run(self, n_pairs):
+        from .pipelines.registration import RegistrationResult
+        mine = pair_indices(n_pairs, self.world, self.rank)
+        local = self.run_local(mine)
+        assert len(local) == len(mine)
+        per = (n_pairs + self.world - 1) // self.world  # rows per rank, padded
+        buf = np.zeros((max(per, 1), self.ROW))
+        for k, r in enumerate(local):
+            buf[k, :16] = np.asarray(r.transformation_, dtype=np.float64).reshape(16)
+            buf[k, 16:] = (r.fitness_, r.inlier_rmse_, getattr(r, "iterations_", 0))
+        t = self.torch.from_numpy(buf).to(self.device)
+        if self.world > 1:
+            allt = self.torch.zeros((self.world * t.shape[0], self.ROW), dtype=t.dtype, device=self.device)
+            self.dist.all_gather_into_tensor(allt, t, group=self.group)  # results only: rank-major concatenation
+            table = allt.cpu().numpy().reshape(self.world, t.shape[0], self.ROW)
+        else:
+            table = t.cpu().numpy()[None]
+        out = []
+        for p in range(n_pairs):
+            row = table[p % self.world, p // self.world]
+            r = RegistrationResult(row[:16].reshape(4, 4).copy())
+            r.fitness_, r.inlier_rmse_, r.iterations_ = float(row[16]), float(row[17]), int(row[18])
+            out.append(r)
+        return out
+
+
+def hip_batch_runner(sources, targets, max_correspondence_distance, inits=None, estimation=None, criteria=None, n_workers=0, ctx=None):
+    """run_local for ShardedBatch on the HIP library: RegistrationICPBatch over this rank's pairs."""
+    from .pipelines.registration import RegistrationICPBatch
+
+    def run(indices):
+        if not indices:
+            return []
+        return RegistrationICPBatch([sources[i] for i in indices], [targets[i] for i in indices], max_correspondence_distance,
+                                    None if inits is None else [inits[i] for i in indices], estimation, criteria,
+                                    n_workers=n_workers, want_corr=False, ctx=ctx)
+    return run

@@ -292,3 +292,21 @@ def test_evaluate_hypotheses_matches_oracle(ctx, oracle):
     f0, r0, b0 = reg.EvaluateHypotheses(src, tgt, 0.0, Ts[:3], ctx=ctx)
     assert not f0.any() and b0 is None
     assert reg.EvaluateHypotheses(src, tgt, r, [far], ctx=ctx)[2] is None
+
+
+def test_sharded_batch_runner_on_one_gpu(ctx):
+    """ShardedBatch + hip_batch_runner with a single rank: the list RegistrationICPBatch gives, in pair order."""
+    geometry, reg = _reg()
+    from open3d_amd.sharded import ShardedBatch, hip_batch_runner
+    S, T_ = [], []
+    for k in range(5):
+        sc = make_scene(1500 + 100 * k, 1800, cfg_id=400 + k)
+        S.append(geometry.PointCloud(sc["source"]))
+        T_.append(geometry.PointCloud(sc["target"]))
+    r = 3 * sc["spacing"]
+    est, crit = reg.TransformationEstimationPointToPoint(), reg.ICPConvergenceCriteria()
+    got = ShardedBatch(hip_batch_runner(S, T_, r, None, est, crit, n_workers=2, ctx=ctx)).run(len(S))
+    want = reg.RegistrationICPBatch(S, T_, r, None, est, crit, n_workers=2, ctx=ctx)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.transformation_, b.transformation_)
+        assert a.fitness_ == b.fitness_ and a.inlier_rmse_ == b.inlier_rmse_ and a.iterations_ == b.iterations_

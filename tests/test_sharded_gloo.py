@@ -171,3 +171,62 @@ def test_shard_bounds_cover_everything():
             b = [shard_bounds(n, w, r) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def _batch_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from conftest import make_scene
+    from open3d_amd.pipelines.registration import RegistrationResult
+    from open3d_amd.sharded import ShardedBatch, pair_indices
+    import oracle
+    oracle.set_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ran = []
+
+    def run_local(indices):  # stand-in for hip_batch_runner: the oracle's RegistrationICP on this rank's pairs
+        out = []
+        for p in indices:
+            sc = make_scene(600, 700, cfg_id=300 + p)
+            o = oracle.registration_icp(sc["source"], sc["target"], 3 * sc["spacing"], None, 1, None)
+            r = RegistrationResult(o.transformation)
+            r.fitness_, r.inlier_rmse_, r.iterations_ = o.fitness, o.inlier_rmse, o.iterations
+            out.append(r)
+            ran.append(p)
+        return out
+
+    n_pairs = 5  # odd: the ranks hold different numbers of pairs
+    res = ShardedBatch(run_local, None, torch.device("cpu")).run(n_pairs)
+    assert ran == pair_indices(n_pairs, world, rank)
+    np.savez(os.path.join(tmpdir, "batch%d.npz" % rank), T=np.stack([r.transformation_ for r in res]),
+             s=np.array([[r.fitness_, r.inlier_rmse_, r.iterations_] for r in res]), ran=np.array(ran))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batch_pairs_dealt_over_two_ranks(oracle, tmp_path):
+    """BASELINE config 5: independent pairs spread over ranks, no data-path collective; every rank returns the whole list
+    in pair order, identical to registering the pairs one by one."""
+    import torch.multiprocessing as mp
+    from conftest import make_scene
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_batch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "batch%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(outs[0]["T"], outs[1]["T"]) and np.array_equal(outs[0]["s"], outs[1]["s"])
+    assert sorted(list(outs[0]["ran"]) + list(outs[1]["ran"])) == [0, 1, 2, 3, 4]
+    assert list(outs[0]["ran"]) == [0, 2, 4] and list(outs[1]["ran"]) == [1, 3]
+    for p in range(5):
+        sc = make_scene(600, 700, cfg_id=300 + p)
+        o = oracle.registration_icp(sc["source"], sc["target"], 3 * sc["spacing"], None, 1, None)
+        assert np.array_equal(outs[0]["T"][p], o.transformation)
+        assert outs[0]["s"][p][0] == o.fitness and outs[0]["s"][p][1] == o.inlier_rmse and int(outs[0]["s"][p][2]) == o.iterations
+    from open3d_amd.sharded import pair_indices
+    for n in (0, 1, 5, 4096):
+        for w in (1, 2, 8):
+            got = sorted(sum((pair_indices(n, w, r) for r in range(w)), []))
+            assert got == list(range(n))
