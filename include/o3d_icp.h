@@ -286,6 +286,19 @@ O3D_API int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double 
                                                      int64_t *out_n_corr, double *out_fitness, double *out_rmse,
                                                      int *out_counts);
 
+/* RegistrationRANSACBasedOnCorrespondence, Registration.cpp:170-197: min(max_iteration, max_validation) rounds of
+ * {sample ransac_n of the given correspondences (:184-186), ComputeTransformation (:187), evaluate the transformed source
+ * against the whole correspondence list (EvaluateRANSACBasedOnCorrespondence, :93-116)}, all rounds in one batch on the
+ * device; sampling from std::mt19937(seed) on the host (seed < 0: std::random_device).  corres: n_corres x {source index,
+ * target index}.  out_inlier (n_corres flags, nullable): the correspondences kept in the result's correspondence_set_.
+ * Empty result for ransac_n < 3, n_corres < ransac_n or max_dist <= 0 (:176-178). */
+O3D_API int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz,
+                                                   const double *tgt_normals, int64_t n_tgt, const int32_t *corres,
+                                                   int64_t n_corres, double max_dist, int estimation, int with_scaling,
+                                                   int ransac_n, int max_iteration, int max_validation, int64_t seed, int mem,
+                                                   double *out_T, int32_t *out_inlier, int64_t *out_n_inlier,
+                                                   double *out_fitness, double *out_rmse);
+
 #ifdef __cplusplus
 }
 #endif

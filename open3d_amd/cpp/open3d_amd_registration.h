@@ -599,6 +599,36 @@ inline RegistrationResult RegistrationRANSACBasedOnFeatureMatching(
   return result;
 }
 
+// RegistrationRANSACBasedOnCorrespondence, Registration.cpp:170-197
+inline RegistrationResult RegistrationRANSACBasedOnCorrespondence(
+    const o3d_types::PointCloud &source, const o3d_types::PointCloud &target, const CorrespondenceSet &corres,
+    double max_correspondence_distance, const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false),
+    int ransac_n = 6, const RANSACConvergenceCriteria &criteria = RANSACConvergenceCriteria(), int64_t seed = -1,
+    Context &c = Context::Default()) {
+  static_assert(sizeof(corres[0]) == 2 * sizeof(int32_t), "CorrespondenceSet must be pairs of 32-bit ints");
+  if (!IsAccelerated(estimation))
+    throw std::runtime_error("open3d_amd: RegistrationRANSACBasedOnCorrespondence needs a point-to-point or point-to-plane estimation");
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  int with_scaling = 0;
+  if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
+  RegistrationResult result;
+  std::vector<int32_t> inlier(corres.size());
+  int64_t n_in = 0;
+  double T[16];
+  Check(c.get(), o3d_registration_ransac_correspondence(
+                     c.get(), (const double *)source.points_.data(), (int64_t)source.points_.size(),
+                     (const double *)target.points_.data(), target.HasNormals() ? (const double *)target.normals_.data() : nullptr,
+                     (int64_t)target.points_.size(), (const int32_t *)corres.data(), (int64_t)corres.size(),
+                     max_correspondence_distance, p2l ? O3D_EST_POINT_TO_PLANE : O3D_EST_POINT_TO_POINT, with_scaling, ransac_n,
+                     criteria.max_iteration_, criteria.max_validation_, seed, O3D_MEM_HOST, T, inlier.data(), &n_in,
+                     &result.fitness_, &result.inlier_rmse_));
+  for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
+  result.correspondence_set_.reserve((size_t)n_in);
+  for (size_t k = 0; k < corres.size(); k++)
+    if (inlier[k]) result.correspondence_set_.push_back(corres[k]);   // Registration.cpp:105
+  return result;
+}
+
 // GetInformationMatrixFromPointClouds, Registration.cpp:303-355
 inline o3d_types::Mat6 GetInformationMatrixFromPointClouds(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                                            double max_correspondence_distance,

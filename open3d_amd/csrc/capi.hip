@@ -1199,4 +1199,109 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
   return st;
 }
 
+int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz,
+                                           const double *tgt_normals, int64_t n_tgt, const int32_t *corres, int64_t n_corres,
+                                           double max_dist, int estimation, int with_scaling, int ransac_n, int max_iteration,
+                                           int max_validation, int64_t seed, int mem, double *out_T, int32_t *out_inlier,
+                                           int64_t *out_n_inlier, double *out_fitness, double *out_rmse) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (n_src < 0 || n_tgt < 0 || n_corres < 0 || (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz) || (n_corres > 0 && !corres))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "RegistrationRANSACBasedOnCorrespondence: bad arguments");
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "RegistrationRANSACBasedOnCorrespondence: estimation type %d is not on the device path",
+                    estimation);
+  if (n_corres >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "more than 2^31-1 correspondences");
+  DeviceGuard guard(ctx->device);
+  static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double bestT[16];
+  memcpy(bestT, kIdentity, sizeof(bestT));
+  double bf = 0.0, br = 0.0;
+  int64_t bgood = 0;
+  int best = -1;
+  const int n_hyp = std::min(max_iteration, max_validation);  // :183
+  auto write_out = [&](const int32_t *d_mask) -> int {
+    if (out_T) memcpy(out_T, bestT, sizeof(bestT));
+    if (out_n_inlier) *out_n_inlier = bgood;
+    if (out_fitness) *out_fitness = bf;
+    if (out_rmse) *out_rmse = br;
+    if (out_inlier && n_corres > 0) {
+      if (d_mask) {
+        O3D_HIP(ctx, hipMemcpyAsync(out_inlier, d_mask, sizeof(int32_t) * (size_t)n_corres,
+                                    mem == O3D_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+      } else if (mem == O3D_MEM_DEVICE) {
+        O3D_HIP(ctx, hipMemsetAsync(out_inlier, 0, sizeof(int32_t) * (size_t)n_corres, ctx->stream));
+      } else {
+        memset(out_inlier, 0, sizeof(int32_t) * (size_t)n_corres);
+      }
+      O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return O3D_OK;
+  };
+  if (ransac_n < 3 || n_corres < ransac_n || !(max_dist > 0.0) || n_hyp <= 0) return write_out(nullptr);  // :176-178
+  ctx->icp_ready = 0;  // scratch slots of the loop are reused
+
+  DevBufs b;
+  const double *d_src, *d_tgt, *d_tnrm;
+  const int32_t *d_corres;
+  O3D_TRY(b.in(ctx, src_xyz, 3 * (size_t)n_src, mem, &d_src));
+  O3D_TRY(b.in(ctx, tgt_xyz, 3 * (size_t)n_tgt, mem, &d_tgt));
+  O3D_TRY(b.in(ctx, tgt_normals, 3 * (size_t)n_tgt, mem, &d_tnrm));
+  O3D_TRY(b.in(ctx, corres, 2 * (size_t)n_corres, mem, &d_corres));
+  std::vector<int32_t> hc;  // host copy of the list for the sampling
+  const int32_t *h_corres = corres;
+  if (mem == O3D_MEM_DEVICE) {
+    hc.resize(2 * (size_t)n_corres);
+    O3D_HIP(ctx, hipMemcpyAsync(hc.data(), corres, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h_corres = hc.data();
+  }
+  std::mt19937 rng;
+  if (seed < 0) {
+    std::random_device rd;
+    rng.seed(rd());
+  } else {
+    rng.seed((uint32_t)seed);
+  }
+  std::uniform_int_distribution<int> pick(0, (int)n_corres - 1);
+  std::vector<int32_t> sets(2 * (size_t)ransac_n * (size_t)n_hyp);
+  for (size_t k = 0; k < (size_t)ransac_n * (size_t)n_hyp; k++) {  // :184-186
+    const int c = pick(rng);
+    sets[2 * k] = h_corres[2 * (size_t)c];
+    sets[2 * k + 1] = h_corres[2 * (size_t)c + 1];
+  }
+  int32_t *d_sets, *d_ok, *d_mask;
+  double *d_T, *d_res;
+  O3D_TRY(b.tmp(ctx, sets.size(), &d_sets));
+  O3D_TRY(b.tmp(ctx, (size_t)n_hyp, &d_ok));
+  O3D_TRY(b.tmp(ctx, 16 * (size_t)n_hyp, &d_T));
+  O3D_TRY(b.tmp(ctx, 2 * (size_t)n_hyp, &d_res));
+  O3D_TRY(b.tmp(ctx, (size_t)n_corres, &d_mask));
+  O3D_HIP(ctx, hipMemcpyAsync(d_sets, sets.data(), sizeof(int32_t) * sets.size(), hipMemcpyHostToDevice, ctx->stream));
+  RansacArgs ra;
+  fill_ransac_args(ra, d_src, nullptr, n_src, d_tgt, d_tnrm, n_tgt, ransac_n, estimation, with_scaling, -1.0, -1.0, -1.0);
+  ra.corres = d_sets; ra.n_hyp = n_hyp; ra.out_T = d_T; ra.out_ok = d_ok;
+  auto run = [&]() -> int {
+    O3D_TRY(o3d_launch_ransac_hypotheses(ctx, ra));  // :187
+    O3D_TRY(o3d_ransac_corr_eval_device(ctx, d_T, n_hyp, d_src, n_src, d_tgt, n_tgt, d_corres, n_corres, max_dist, d_res));  // :188-190
+    std::vector<double> res(2 * (size_t)n_hyp), Ts(16 * (size_t)n_hyp);
+    O3D_HIP(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipMemcpyAsync(Ts.data(), d_T, sizeof(double) * Ts.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int h = 0; h < n_hyp; h++) {  // :191-193, in iteration order
+      const double good = res[2 * (size_t)h];
+      const double fit = good > 0.0 ? good / (double)n_corres : 0.0;
+      const double rm = good > 0.0 ? sqrt(res[2 * (size_t)h + 1] / good) : 0.0;
+      if (fit > bf || (fit == bf && rm < br)) { bf = fit; br = rm; bgood = (int64_t)good; best = h; }
+    }
+    if (best < 0) return write_out(nullptr);
+    memcpy(bestT, Ts.data() + 16 * (size_t)best, sizeof(bestT));
+    O3D_TRY(o3d_ransac_corr_mask_device(ctx, d_T + 16 * (size_t)best, d_src, n_src, d_tgt, n_tgt, d_corres, n_corres, max_dist, d_mask));
+    return write_out(d_mask);
+  };
+  const int st = run();
+  (void)hipStreamSynchronize(ctx->stream);
+  return st;
+}
+
 }  // extern "C"

@@ -165,6 +165,10 @@ struct RansacArgs {
   int32_t *out_ok;    // n_hyp
 };
 int o3d_launch_ransac_hypotheses(o3d_ctx *ctx, const RansacArgs &a);
+int o3d_ransac_corr_eval_device(o3d_ctx *ctx, const double *d_Ts, int n_hyp, const double *d_src, int64_t n_src, const double *d_tgt,
+                                int64_t n_tgt, const int32_t *d_corres, int64_t n_c, double max_dist, double *d_out);
+int o3d_ransac_corr_mask_device(o3d_ctx *ctx, const double *d_T, const double *d_src, int64_t n_src, const double *d_tgt, int64_t n_tgt,
+                                const int32_t *d_corres, int64_t n_c, double max_dist, int32_t *d_mask);
 int o3d_feature_nn_device(o3d_ctx *ctx, const double *d_src_feat, int64_t n_src, const double *d_tgt_feat, int64_t n_tgt, int dim,
                           const int32_t *d_query_ids, int64_t n_q, int32_t *d_out_index, double *d_out_d2);
 

@@ -117,7 +117,107 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_feature_nn_merge(const double *__
   if (out_d2) out_d2[q] = bi >= 0 ? best : 0.0;
 }
 
+// EvaluateRANSACBasedOnCorrespondence, Registration.cpp:93-116, for a batch of transformations: workgroup (h, c) takes
+// hypothesis h and the c-th slice of the correspondence list.  part: [h][c][2] = {good, error2}.  The source is moved by
+// T as PointCloud::Transform does (Geometry3D.cpp:77-82: 4x4 * (p, 1), divided by w unless the last row is (0,0,0,1)).
+__device__ __forceinline__ bool corr_pair_d2(const double *__restrict__ T, const double *__restrict__ src, const double *__restrict__ tgt,
+                                             const int32_t *__restrict__ c, int64_t n_src, int64_t n_tgt, double &d2) {
+  const int32_t i = c[0], j = c[1];
+  if (i < 0 || i >= n_src || j < 0 || j >= n_tgt) return false;
+  const double x = src[3 * (size_t)i], y = src[3 * (size_t)i + 1], z = src[3 * (size_t)i + 2];
+  double v[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double t = T[r] * x;
+    t = t + T[4 + r] * y;
+    t = t + T[8 + r] * z;
+    v[r] = t + T[12 + r];
+  }
+  if (!(T[3] == 0.0 && T[7] == 0.0 && T[11] == 0.0 && T[15] == 1.0)) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+  const double dx = v[0] - tgt[3 * (size_t)j], dy = v[1] - tgt[3 * (size_t)j + 1], dz = v[2] - tgt[3 * (size_t)j + 2];
+  d2 = dx * dx;
+  d2 = d2 + dy * dy;
+  d2 = d2 + dz * dz;
+  return true;
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_ransac_corr_eval(const double *__restrict__ Ts, const double *__restrict__ src,
+                                                                 int64_t n_src, const double *__restrict__ tgt, int64_t n_tgt,
+                                                                 const int32_t *__restrict__ corres, int64_t n_c, double max_d2,
+                                                                 double *__restrict__ part) {
+  __shared__ double red[O3D_BLOCK / O3D_WAVE][2];
+  const double *T = Ts + 16 * (size_t)blockIdx.x;
+  const int64_t per = (n_c + gridDim.y - 1) / gridDim.y;
+  const int64_t k0 = (int64_t)blockIdx.y * per, k1 = k0 + per < n_c ? k0 + per : n_c;
+  double good = 0.0, err = 0.0;
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += O3D_BLOCK) {
+    double d2;
+    if (corr_pair_d2(T, src, tgt, corres + 2 * k, n_src, n_tgt, d2) && d2 < max_d2) { good += 1.0; err += d2; }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    good += __shfl_xor(good, d, O3D_WAVE);
+    err += __shfl_xor(err, d, O3D_WAVE);
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = good; red[threadIdx.x >> 6][1] = err; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double g = red[0][0], e = red[0][1];
+    for (int w = 1; w < O3D_BLOCK / O3D_WAVE; w++) { g += red[w][0]; e += red[w][1]; }
+    part[2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y)] = g;
+    part[2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y) + 1] = e;
+  }
+}
+
+// out: [h][2] = {good, error2}, slices added in order (run-to-run deterministic)
+__global__ __launch_bounds__(O3D_BLOCK) void k_ransac_corr_finish(const double *__restrict__ part, int n_hyp, int n_slices,
+                                                                   double *__restrict__ out) {
+  const int h = blockIdx.x * O3D_BLOCK + threadIdx.x;
+  if (h >= n_hyp) return;
+  double g = 0.0, e = 0.0;
+  for (int c = 0; c < n_slices; c++) { g += part[2 * ((size_t)h * n_slices + c)]; e += part[2 * ((size_t)h * n_slices + c) + 1]; }
+  out[2 * (size_t)h] = g;
+  out[2 * (size_t)h + 1] = e;
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_ransac_corr_mask(const double *__restrict__ T, const double *__restrict__ src, int64_t n_src,
+                                                                 const double *__restrict__ tgt, int64_t n_tgt,
+                                                                 const int32_t *__restrict__ corres, int64_t n_c, double max_d2,
+                                                                 int32_t *__restrict__ mask) {
+  for (int64_t k = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; k < n_c; k += (int64_t)gridDim.x * O3D_BLOCK) {
+    double d2;
+    mask[k] = (corr_pair_d2(T, src, tgt, corres + 2 * k, n_src, n_tgt, d2) && d2 < max_d2) ? 1 : 0;
+  }
+}
+
 }  // namespace
+
+// d_out: n_hyp x {good, error2} (device).  All pointers device pointers.
+int o3d_ransac_corr_eval_device(o3d_ctx *ctx, const double *d_Ts, int n_hyp, const double *d_src, int64_t n_src, const double *d_tgt,
+                                int64_t n_tgt, const int32_t *d_corres, int64_t n_c, double max_dist, double *d_out) {
+  if (n_hyp <= 0) return O3D_OK;
+  int64_t slices = (O3D_NUM_CU * 8 + n_hyp - 1) / n_hyp;
+  slices = std::max<int64_t>(1, std::min<int64_t>(slices, (n_c + 4 * O3D_BLOCK - 1) / (4 * O3D_BLOCK)));
+  slices = std::min<int64_t>(slices, 65535);
+  void *part = nullptr;
+  O3D_TRY(o3d_scratch(ctx, 1, sizeof(double) * 2 * (size_t)n_hyp * (size_t)slices, &part));
+  hipLaunchKernelGGL(k_ransac_corr_eval, dim3((unsigned)n_hyp, (unsigned)slices), dim3(O3D_BLOCK), 0, ctx->stream, d_Ts, d_src, n_src,
+                     d_tgt, n_tgt, d_corres, n_c, max_dist * max_dist, (double *)part);
+  hipLaunchKernelGGL(k_ransac_corr_finish, dim3((unsigned)((n_hyp + O3D_BLOCK - 1) / O3D_BLOCK)), dim3(O3D_BLOCK), 0, ctx->stream,
+                     (const double *)part, n_hyp, (int)slices, d_out);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+int o3d_ransac_corr_mask_device(o3d_ctx *ctx, const double *d_T, const double *d_src, int64_t n_src, const double *d_tgt, int64_t n_tgt,
+                                const int32_t *d_corres, int64_t n_c, double max_dist, int32_t *d_mask) {
+  if (n_c <= 0) return O3D_OK;
+  const int64_t g = std::max<int64_t>(1, std::min<int64_t>((n_c + O3D_BLOCK - 1) / O3D_BLOCK, O3D_MAX_GRID));
+  hipLaunchKernelGGL(k_ransac_corr_mask, dim3((unsigned)g), dim3(O3D_BLOCK), 0, ctx->stream, d_T, d_src, n_src, d_tgt, n_tgt, d_corres,
+                     n_c, max_dist * max_dist, d_mask);
+  O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
 
 // All pointers are device pointers.  d_query_ids may be null (queries = all source columns, n_q = n_src).
 int o3d_feature_nn_device(o3d_ctx *ctx, const double *d_src_feat, int64_t n_src, const double *d_tgt_feat, int64_t n_tgt, int dim,

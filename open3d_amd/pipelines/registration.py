@@ -395,6 +395,33 @@ def RegistrationRANSACBasedOnFeatureMatching(source, target, source_feature, tar
     return res
 
 
+def RegistrationRANSACBasedOnCorrespondence(source, target, corres, max_correspondence_distance, estimation=None, ransac_n=6,
+                                            criteria=None, seed=-1, ctx=None):
+    """RegistrationRANSACBasedOnCorrespondence, Registration.cpp:170-197.  corres: n x 2 {source index, target index}.
+    correspondence_set_ of the result = the listed pairs within the distance under the returned transformation."""
+    ctx = ctx or _lib.default_context()
+    estimation = estimation or TransformationEstimationPointToPoint(False)
+    criteria = criteria or RANSACConvergenceCriteria()
+    src = np.ascontiguousarray(source.points_, dtype=np.float64)
+    tgt = np.ascontiguousarray(target.points_, dtype=np.float64)
+    tnrm = np.ascontiguousarray(target.normals_, dtype=np.float64) if target.HasNormals() else None
+    c = np.ascontiguousarray(np.asarray(corres, np.int32).reshape(-1, 2))
+    T = np.zeros(16)
+    mask = np.zeros(max(len(c), 1), np.int32)
+    n_in = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    ctx.check(ctx._lib.o3d_registration_ransac_correspondence(
+        ctx.handle, _lib.ptr(src), len(src), _lib.ptr(tgt), _lib.ptr(tnrm), len(tgt), _lib.ptr(c), len(c),
+        float(max_correspondence_distance), estimation.GetTransformationEstimationType(),
+        int(getattr(estimation, "with_scaling_", False)), int(ransac_n), criteria.max_iteration_, criteria.max_validation_, int(seed),
+        _lib.MEM_HOST, T.ctypes.data_as(_lib.c_dp), _lib.ptr(mask), C.byref(n_in), C.byref(fit), C.byref(rmse)))
+    res = RegistrationResult(_lib.from_colmajor(T))
+    res.fitness_, res.inlier_rmse_, res.n_corr_ = fit.value, rmse.value, n_in.value
+    res.inlier_mask_ = mask[: len(c)].astype(bool)
+    res.correspondence_set_ = c[res.inlier_mask_]
+    return res
+
+
 def EvaluateHypotheses(source, target, max_correspondence_distance, transformations, want_corr=True, ctx=None):
     """The validation step of RegistrationRANSACBasedOnFeatureMatching (Registration.cpp:269-275) for a list of candidate
     transformations.  Returns (fitness[k], inlier_rmse[k], best RegistrationResult or None): `best` is the hypothesis

@@ -307,6 +307,19 @@ def ransac_check(src, tgt, corres, T, edge_sim=-1.0, dist_thr=-1.0, normal_angle
                   C.c_double(dist_thr), C.c_double(normal_angle)))
 
 
+def ransac_corr_evaluate(src, tgt, corres, T, max_dist):
+    """EvaluateRANSACBasedOnCorrespondence, Registration.cpp:93-116 -> (fitness, rmse, inlier mask)."""
+    c = np.ascontiguousarray(corres, np.int32)
+    mask = np.zeros(max(len(c), 1), np.int32)
+    e = C.c_double()
+    f = lib().orc_ransac_corr_evaluate
+    f.restype = C.c_int64
+    good = f(_d(_pts(src)), _d(_pts(tgt)), _i(c), C.c_int64(len(c)), _d(_mat(T)), C.c_double(max_dist), C.byref(e), _i(mask))
+    if good == 0:
+        return 0.0, 0.0, mask[: len(c)].astype(bool)
+    return good / len(c), float(np.sqrt(e.value / good)), mask[: len(c)].astype(bool)
+
+
 def voxel_down_sample(pts, voxel, normals=None, colors=None):
     """PointCloud.cpp:273-306 -> (points, normals|None, colors|None, voxel_index int32[M,3]); sorted by (z,y,x)."""
     pts = _pts(pts)

@@ -1546,3 +1546,27 @@ ORC_EXPORT int orc_ransac_check(const double *src, const double *snrm, const dou
   }
   return 1;
 }
+
+/* EvaluateRANSACBasedOnCorrespondence, Registration.cpp:93-116: `src` is moved by T (PointCloud::Transform,
+ * Geometry3D.cpp:77-82), every listed pair with squared distance < max_dist^2 is kept.  Returns the number kept; *err2 =
+ * sum of their squared distances (serial, in list order); mask[k] = 1 for kept pairs (nullable). */
+ORC_EXPORT int64_t orc_ransac_corr_evaluate(const double *src, const double *tgt, const int32_t *c, int64_t n_c, const double *T,
+                                            double max_dist, double *err2, int32_t *mask) {
+  const double max_d2 = max_dist * max_dist;
+  const int affine = (T[3] == 0.0 && T[7] == 0.0 && T[11] == 0.0 && T[15] == 1.0);
+  int64_t good = 0;
+  double e = 0.0;
+  for (int64_t k = 0; k < n_c; k++) {
+    const double *s = src + 3 * (size_t)c[2 * k], *t = tgt + 3 * (size_t)c[2 * k + 1];
+    double v[4];
+    for (int r = 0; r < 4; r++) v[r] = ((T[r] * s[0] + T[4 + r] * s[1]) + T[8 + r] * s[2]) + T[12 + r];
+    if (!affine) { v[0] /= v[3]; v[1] /= v[3]; v[2] /= v[3]; }
+    const double dx = v[0] - t[0], dy = v[1] - t[1], dz = v[2] - t[2];
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
+    const int in = d2 < max_d2;
+    if (in) { good++; e += d2; }
+    if (mask) mask[k] = in;
+  }
+  *err2 = e;
+  return good;
+}

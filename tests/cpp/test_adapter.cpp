@@ -140,6 +140,13 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 16; i++) put(out, gr.transformation_.m[i]);
   put(out, gr.fitness_); put(out, gr.inlier_rmse_); put(out, (double)gr.correspondence_set_.size());
 
+  // RANSAC over the ICP result's own correspondence set (all inliers): the estimate must keep (nearly) all of them
+  reg::RegistrationResult rc = reg::RegistrationRANSACBasedOnCorrespondence(source, target, r.correspondence_set_, radius,
+                                                                            reg::TransformationEstimationPointToPoint(false), 6,
+                                                                            reg::RANSACConvergenceCriteria(200, 200), 11);
+  for (int i = 0; i < 16; i++) put(out, rc.transformation_.m[i]);
+  put(out, rc.fitness_); put(out, rc.inlier_rmse_); put(out, (double)rc.correspondence_set_.size());
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(out.data(), 8, out.size(), f);

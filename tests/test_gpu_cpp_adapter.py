@@ -96,4 +96,11 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
     assert out[o + 16] == gw.fitness_ and out[o + 17] == gw.inlier_rmse_ and int(out[o + 18]) == len(gw.correspondence_set_)
     assert gw.fitness_ > 0.5
     o += 19
+    cw2 = reg.RegistrationRANSACBasedOnCorrespondence(src_pc, tgt_pc, want.correspondence_set_, radius,
+                                                      reg.TransformationEstimationPointToPoint(False), 6,
+                                                      reg.RANSACConvergenceCriteria(200, 200), seed=11, ctx=ctx)
+    assert np.array_equal(out[o:o + 16].reshape(4, 4).T, cw2.transformation_)
+    assert out[o + 16] == cw2.fitness_ and out[o + 17] == cw2.inlier_rmse_ and int(out[o + 18]) == len(cw2.correspondence_set_)
+    assert cw2.fitness_ > 0.9
+    o += 19
     assert o == len(out)

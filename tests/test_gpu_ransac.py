@@ -155,3 +155,57 @@ def test_ransac_edge_cases(ctx):
     res = reg.RegistrationRANSACBasedOnFeatureMatching(ps, pt, f, f, 0.5, None, 3, None, reg.RANSACConvergenceCriteria(20, 7), seed=1,
                                                        ctx=ctx)
     assert res.validations_ == 7
+
+
+def test_ransac_based_on_correspondence(ctx, oracle):
+    """RegistrationRANSACBasedOnCorrespondence (Registration.cpp:170-197).  The sampling is random (std::mt19937 here,
+    random_device in the reference); what must hold for every run: the returned numbers and inlier set are the oracle's
+    evaluation (:93-116) of the returned transformation, which is ComputeTransformation of SOME ransac_n listed pairs."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(5000, 5000, cfg_id=44, theta_deg=30.0, tau=(30.0, 10.0, -20.0), noise=0.05)
+    src, tgt, s = sc["source"], sc["target"], sc["spacing"]
+    moved = oracle.transform_points(sc["T_true"], src)
+    near = oracle.correspondences(moved, tgt, 5 * s)[0]
+    rng = np.random.default_rng(9)
+    ids = np.flatnonzero(near >= 0)[:3000]
+    c = np.stack([ids, near[ids]], 1).astype(np.int32)
+    bad = rng.random(len(c)) < 0.5                          # half of the list is wrong
+    c[bad, 1] = rng.integers(0, len(tgt), bad.sum())
+    ps, pt = geometry.PointCloud(src), geometry.PointCloud(tgt)
+    r = 1.5 * s
+    # one round per call: the evaluation of 40 different sampled transformations against the oracle
+    hits = 0
+    for seed in range(40):
+        res = reg.RegistrationRANSACBasedOnCorrespondence(ps, pt, c, r, None, 3, reg.RANSACConvergenceCriteria(1, 1), seed=seed, ctx=ctx)
+        fit, rmse, mask = oracle.ransac_corr_evaluate(src, tgt, c, res.transformation_, r)
+        if fit == 0.0:   # the reference keeps RegistrationResult(): identity, nothing
+            assert res.fitness_ == 0.0 and np.array_equal(res.transformation_, np.eye(4)) and not res.inlier_mask_.any()
+            continue
+        hits += 1
+        assert res.fitness_ == fit and rel_err(res.inlier_rmse_, rmse) < 1e-12
+        assert np.array_equal(res.inlier_mask_, mask) and np.array_equal(res.correspondence_set_, c[mask])
+    assert hits > 0
+    # the default-sized run finds the motion despite 50 % outliers, reproducibly for a given seed
+    res = reg.RegistrationRANSACBasedOnCorrespondence(ps, pt, c, r, reg.TransformationEstimationPointToPoint(False), 6,
+                                                      reg.RANSACConvergenceCriteria(4000, 4000), seed=3, ctx=ctx)
+    fit, rmse, mask = oracle.ransac_corr_evaluate(src, tgt, c, res.transformation_, r)
+    assert res.fitness_ == fit and rel_err(res.inlier_rmse_, rmse) < 1e-12 and np.array_equal(res.inlier_mask_, mask)
+    assert res.fitness_ > 0.35 and (mask & ~bad).sum() > 0.7 * (~bad).sum()
+    again = reg.RegistrationRANSACBasedOnCorrespondence(ps, pt, c, r, reg.TransformationEstimationPointToPoint(False), 6,
+                                                        reg.RANSACConvergenceCriteria(4000, 4000), seed=3, ctx=ctx)
+    assert np.array_equal(again.transformation_, res.transformation_)
+    moved_est = oracle.transform_points(res.transformation_, src)
+    assert np.sqrt(((moved_est - moved) ** 2).sum(1)).mean() < 2 * s
+    # point-to-plane estimation over the samples (needs target normals; identity updates without them)
+    tn = oracle.estimate_normals(tgt, oracle.HYBRID, 30, 4 * s)
+    res = reg.RegistrationRANSACBasedOnCorrespondence(ps, geometry.PointCloud(tgt, normals=tn), c, r,
+                                                      reg.TransformationEstimationPointToPlane(), 6,
+                                                      reg.RANSACConvergenceCriteria(500, 500), seed=3, ctx=ctx)
+    fit, rmse, mask = oracle.ransac_corr_evaluate(src, tgt, c, res.transformation_, r)
+    assert res.fitness_ == fit and np.array_equal(res.inlier_mask_, mask)
+    # :176-178
+    for kw in (dict(ransac_n=2), dict(r=0.0), dict(c=c[:2])):
+        out = reg.RegistrationRANSACBasedOnCorrespondence(ps, pt, kw.get("c", c), kw.get("r", r), None, kw.get("ransac_n", 3),
+                                                          reg.RANSACConvergenceCriteria(10, 10), seed=1, ctx=ctx)
+        assert out.fitness_ == 0.0 and np.array_equal(out.transformation_, np.eye(4)) and len(out.correspondence_set_) == 0
