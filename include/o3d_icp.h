@@ -245,6 +245,18 @@ O3D_API int o3d_radius_neighbor_count(o3d_ctx *ctx, const double *xyz, int64_t n
  * cloud statistics and the threshold (:453-466) are a serial pass over these values on the caller's side. */
 O3D_API int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_neighbors, int mem, double *out_mean);
 
+/* EstimateNormals split over GPUs (no counterpart in the reference, whose loop EstimateNormals.cpp:330-350 is
+ * per point and independent).  Every rank builds the same grid over the whole cloud; shard g of G computes the normals of
+ * positions [g * rows, min(ng, (g + 1) * rows)) of the cell-ordered cloud, rows = ceil(ng / G), ng = number of finite points
+ * (*out_ng), and writes them in that order to out_part (rows x 3, padding rows zero).  oriented (nullable): existing normals
+ * to orient against (EstimateNormals.cpp:343-346).  After the ranks' parts have been all-gathered in rank order,
+ * o3d_estimate_normals_assemble -- on the same context, directly afterwards -- scatters them to the caller's order;
+ * the result is bit-identical to o3d_estimate_normals. */
+O3D_API int o3d_estimate_normals_shard(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                                       const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng);
+O3D_API int o3d_estimate_normals_assemble(o3d_ctx *ctx, const double *xyz, int64_t n, const double *all_parts, int n_shards, int mem,
+                                          double *normals);
+
 /* ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159 (SPFH :71-111, pair features :39-69).  search_type KNN
  * or HYBRID (knn / max_nn <= 128).  out_feature: 33 doubles per point, the storage of Feature::data_ (33 x n, column-major). */
 O3D_API int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *normals, int64_t n, int search_type, int knn,

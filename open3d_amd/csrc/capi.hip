@@ -30,6 +30,10 @@ int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_n
                             int max_nn, double *d_grad);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
                                int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
+int o3d_estimate_normals_shard_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                                    const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng);
+int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t n, const double *all_parts, int n_shards, int mem,
+                                       double *normals);
 int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                               double *normals, int has_normals);
 
@@ -907,6 +911,22 @@ int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_
   O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
   return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
+}
+
+int o3d_estimate_normals_shard(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                               const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_estimate_normals_shard_impl(ctx, xyz, n, search_type, knn, radius, mem, oriented, shard, n_shards, out_part, out_ng);
+}
+
+int o3d_estimate_normals_assemble(o3d_ctx *ctx, const double *xyz, int64_t n, const double *all_parts, int n_shards, int mem,
+                                  double *normals) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  return o3d_estimate_normals_assemble_impl(ctx, xyz, n, all_parts, n_shards, mem, normals);
 }
 
 int o3d_compute_point_cloud_distance(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, int64_t n_tgt, int mem,

@@ -318,10 +318,14 @@ __device__ __forceinline__ void klist_sort(KList &l) {
 //   MODE 1 Radius: every point with d2 < thr in the 3x3x3 block; cumulants summed in traversal order (the reference
 //          sums in ascending distance: same set, rounding-level difference only).
 //   MODE 2 Hybrid: the max_nn nearest with d2 < thr.
+//   Positions [p_lo, p_hi) of the cell-ordered cloud are processed (a shard of it when the cloud is split over GPUs);
+//   by_pos = 0: the normal of a point goes to normals[original index]; 1: to normals[position - p_lo] (shard output).
+//   The orientation reference (has_normals) is read from `ref` by original index (ref may alias normals when by_pos = 0).
 template <int MODE>
-__global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *__restrict__ pts, int64_t n_grid,
+__global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *__restrict__ pts, int64_t p_lo, int64_t p_hi,
                                                                  const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
-                                                                 double thr, double *__restrict__ normals, int has_normals) {
+                                                                 double thr, double *normals, int has_normals, int by_pos,
+                                                                 const double *ref) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
@@ -332,9 +336,10 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
   l.thr = (MODE == 0) ? INFINITY : thr;
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
 
-  for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
+  for (int64_t p = p_lo + (int64_t)blockIdx.x * kNrmBlock + lane; p < p_hi; p += (int64_t)gridDim.x * kNrmBlock) {
     const double4 q = pts[p];
     const size_t qi = (size_t)__double_as_longlong(q.w);
+    const size_t oi = by_pos ? (size_t)(p - p_lo) : qi;
     const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
@@ -419,14 +424,23 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
       cov[5] = cov[7] = c[7] - c[1] * c[2];
       fast_eigen3x3(cov, nv);
       if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
-        if (has_normals) { nv[0] = normals[3 * qi]; nv[1] = normals[3 * qi + 1]; nv[2] = normals[3 * qi + 2]; }
+        if (has_normals) { nv[0] = ref[3 * qi]; nv[1] = ref[3 * qi + 1]; nv[2] = ref[3 * qi + 2]; }
         else { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
       }
-      if (has_normals && nv[0] * normals[3 * qi] + nv[1] * normals[3 * qi + 1] + nv[2] * normals[3 * qi + 2] < 0.0) {
+      if (has_normals && nv[0] * ref[3 * qi] + nv[1] * ref[3 * qi + 1] + nv[2] * ref[3 * qi + 2] < 0.0) {
         nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0;
       }
     }
-    normals[3 * qi] = nv[0]; normals[3 * qi + 1] = nv[1]; normals[3 * qi + 2] = nv[2];
+    normals[3 * oi] = nv[0]; normals[3 * oi + 1] = nv[1]; normals[3 * oi + 2] = nv[2];
+  }
+}
+
+// Shard outputs (cell order, rank-major) -> the caller's order.
+__global__ __launch_bounds__(O3D_BLOCK) void k_normals_scatter(const double4 *__restrict__ pts, int64_t n_grid,
+                                                                const double *__restrict__ parts, double *__restrict__ normals) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const size_t qi = (size_t)__double_as_longlong(pts[p].w);
+    normals[3 * qi] = parts[3 * p]; normals[3 * qi + 1] = parts[3 * p + 1]; normals[3 * qi + 2] = parts[3 * p + 2];
   }
 }
 
@@ -842,32 +856,39 @@ static int build_knn_grid(o3d_ctx *ctx, const double *d_xyz, int64_t n, double *
   return O3D_OK;
 }
 
-int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
-                              double *normals, int has_normals) {
-  if (n < 0 || (n > 0 && (!xyz || !normals))) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: null buffer");
+// shard < 0: the whole cloud, normals written in place (the drop-in call).  shard >= 0 of n_shards: positions
+// [shard * rows, min(ng, (shard + 1) * rows)) of the cell-ordered cloud, rows = ceil(ng / n_shards), written in that order to
+// out_part (rows x 3, `mem` space); `normals` is then only the orientation reference (has_normals).  *out_ng = ng.
+static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                                double *normals, int has_normals, int shard, int n_shards, double *out_part, int64_t *out_ng) {
+  if (n < 0 || (n > 0 && (!xyz || (!normals && (shard < 0 || has_normals)))))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: null buffer");
   if (search_type < 0 || search_type > 2) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: unknown search type %d", search_type);
   if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: more than 2^31-1 points");
+  if (shard >= 0 && (n_shards < 1 || shard >= n_shards || !out_part || !out_ng))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals: bad shard arguments");
+  if (out_ng) *out_ng = 0;
   if (n == 0) return O3D_OK;
   ctx->icp_ready = 0;  // the context's target grid is rebuilt for this cloud
+  const bool sharded = shard >= 0;
   const size_t bytes = sizeof(double) * 3 * (size_t)n;
   const double *d_xyz = xyz;
   double *d_nrm = normals;
-  void *sx = nullptr, *sn = nullptr;
-  if (mem == O3D_MEM_HOST) {
-    O3D_HIP(ctx, hipMalloc(&sx, bytes));
-    hipError_t e = hipMalloc(&sn, bytes);
-    if (e != hipSuccess) { (void)hipFree(sx); return o3d_fail(ctx, O3D_ERR_OOM, "EstimateNormals: %s", hipGetErrorString(e)); }
-    d_xyz = (const double *)sx;
-    d_nrm = (double *)sn;
-  }
+  void *sx = nullptr, *sn = nullptr, *sp = nullptr;
   auto cleanup = [&]() {
-    if (sx) (void)hipFree(sx);
-    if (sn) (void)hipFree(sn);
+    for (void *b : {sx, sn, sp})
+      if (b) (void)hipFree(b);
   };
   auto run = [&]() -> int {
     if (mem == O3D_MEM_HOST) {
+      O3D_HIP(ctx, hipMalloc(&sx, bytes));
       O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
-      if (has_normals) O3D_HIP(ctx, hipMemcpyAsync(sn, normals, bytes, hipMemcpyHostToDevice, ctx->stream));
+      d_xyz = (const double *)sx;
+      if (!sharded || has_normals) {
+        O3D_HIP(ctx, hipMalloc(&sn, bytes));
+        if (has_normals) O3D_HIP(ctx, hipMemcpyAsync(sn, normals, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_nrm = (double *)sn;
+      }
     }
     const bool degenerate = (search_type != O3D_SEARCH_RADIUS && knn < 3) || (search_type != O3D_SEARCH_KNN && !(radius > 0.0));
     if (search_type != O3D_SEARCH_RADIUS && knn > kMaxKnn)
@@ -882,30 +903,104 @@ int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int se
     // (:347-349); run the hybrid kernel with an empty acceptance threshold
     O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, degenerate ? 1.0 : h));
     const int64_t ng = ctx->n_tgt_grid;
+    if (out_ng) *out_ng = ng;
+    int64_t p_lo = 0, p_hi = ng, rows = 0;
+    double *d_out = d_nrm;
+    if (sharded) {
+      rows = (ng + n_shards - 1) / n_shards;
+      p_lo = std::min<int64_t>(ng, (int64_t)shard * rows);
+      p_hi = std::min<int64_t>(ng, p_lo + rows);
+      d_out = out_part;
+      if (mem == O3D_MEM_HOST) {
+        O3D_HIP(ctx, hipMalloc(&sp, sizeof(double) * 3 * (size_t)std::max<int64_t>(rows, 1)));
+        d_out = (double *)sp;
+      }
+      if (rows > 0) O3D_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(double) * 3 * (size_t)rows, ctx->stream));  // padding rows
+    }
     const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126,148
     const int kk = degenerate ? 1 : (search_type == O3D_SEARCH_RADIUS ? 1 : knn);
     const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)kk;
-    int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
+    int64_t g = (p_hi - p_lo + kNrmBlock - 1) / kNrmBlock;
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
-    if (ng > 0) {
+    const int by_pos = sharded ? 1 : 0;
+    const double *ref = d_nrm;
+    if (p_hi > p_lo) {
       if (degenerate) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
-        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
-                           ctx->cell_start, ctx->gp, 1, 0.0, d_nrm, has_normals);
+        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref);
       } else if (search_type == O3D_SEARCH_KNN) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
-        hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
-                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+        hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
       } else if (search_type == O3D_SEARCH_RADIUS) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<1>, lds));
-        hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
-                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+        hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
       } else {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
-        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng,
-                           ctx->cell_start, ctx->gp, kk, thr, d_nrm, has_normals);
+        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
       }
     }
+    if (!sharded && ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);
+    O3D_HIP(ctx, hipGetLastError());
+    if (mem == O3D_MEM_HOST) {
+      if (sharded) {
+        if (rows > 0) O3D_HIP(ctx, hipMemcpyAsync(out_part, d_out, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+      } else {
+        O3D_HIP(ctx, hipMemcpyAsync(normals, d_nrm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return O3D_OK;
+  };
+  const int st = run();
+  cleanup();
+  return st;
+}
+
+int o3d_estimate_normals_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                              double *normals, int has_normals) {
+  return estimate_normals_run(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals, -1, 1, nullptr, nullptr);
+}
+
+int o3d_estimate_normals_shard_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                                    const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng) {
+  return estimate_normals_run(ctx, xyz, n, search_type, knn, radius, mem, const_cast<double *>(oriented), oriented ? 1 : 0, shard,
+                              n_shards, out_part, out_ng);
+}
+
+// all_parts: n_shards x rows x 3 in rank order (rows = ceil(ng / n_shards)) = the normals of the cell-ordered cloud.  Uses the
+// grid the preceding o3d_estimate_normals_shard left in the context.  xyz: the same cloud (non-finite points get (0, 0, 1)).
+int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t n, const double *all_parts, int n_shards, int mem,
+                                       double *normals) {
+  if (n < 0 || n_shards < 1 || (n > 0 && (!xyz || !all_parts || !normals)))
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "EstimateNormals (assemble): bad arguments");
+  if (n == 0) return O3D_OK;
+  if (ctx->n_tgt != n || !ctx->tgt_sorted)
+    return o3d_fail(ctx, O3D_ERR_STATE, "o3d_estimate_normals_assemble must follow o3d_estimate_normals_shard on the same cloud");
+  const int64_t ng = ctx->n_tgt_grid;
+  const int64_t rows = (ng + n_shards - 1) / n_shards;
+  const size_t bytes = sizeof(double) * 3 * (size_t)n, pbytes = sizeof(double) * 3 * (size_t)std::max<int64_t>(rows * n_shards, 1);
+  const double *d_xyz = xyz, *d_parts = all_parts;
+  double *d_nrm = normals;
+  void *sx = nullptr, *sn = nullptr, *sp = nullptr;
+  auto cleanup = [&]() {
+    for (void *b : {sx, sn, sp})
+      if (b) (void)hipFree(b);
+  };
+  auto run = [&]() -> int {
+    if (mem == O3D_MEM_HOST) {
+      O3D_HIP(ctx, hipMalloc(&sx, bytes));
+      O3D_HIP(ctx, hipMalloc(&sn, bytes));
+      O3D_HIP(ctx, hipMalloc(&sp, pbytes));
+      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, hipMemcpyAsync(sp, all_parts, sizeof(double) * 3 * (size_t)(rows * n_shards), hipMemcpyHostToDevice, ctx->stream));
+      d_xyz = (const double *)sx; d_nrm = (double *)sn; d_parts = (const double *)sp;
+    }
+    if (ng > 0)
+      hipLaunchKernelGGL(k_normals_scatter, dim3(grid_for(ng)), dim3(O3D_BLOCK), 0, ctx->stream, ctx->tgt_sorted, ng, d_parts, d_nrm);
     if (ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(normals, d_nrm, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -159,3 +159,67 @@ def hip_batch_runner(sources, targets, max_correspondence_distance, inits=None, 
                                     None if inits is None else [inits[i] for i in indices], estimation, criteria,
                                     n_workers=n_workers, want_corr=False, ctx=ctx)
     return run
+
+
+class HipNormalsEngine:
+    """o3d_estimate_normals_shard / _assemble on host (numpy) buffers."""
+
+    def __init__(self, ctx=None):
+        from . import _lib
+        self._lib = _lib
+        self.ctx = ctx or _lib.default_context()
+
+    def shard(self, points, normals, search_param, shard, n_shards):
+        """-> (part rows x 3 float64, ng)."""
+        import ctypes as C
+        lib, c = self._lib, self.ctx
+        n = len(points)
+        rows = (n + n_shards - 1) // n_shards  # upper bound of ceil(ng / n_shards): ng <= n
+        part = np.zeros((max(rows, 1), 3))
+        ng = C.c_int64()
+        c.check(c._lib.o3d_estimate_normals_shard(c.handle, lib.ptr(points), n, search_param.search_type, search_param.knn_,
+                                                  search_param.radius_, lib.MEM_HOST, lib.ptr(normals), shard, n_shards,
+                                                  lib.ptr(part), C.byref(ng)))
+        rows_ng = (ng.value + n_shards - 1) // n_shards
+        return part[:rows_ng], ng.value
+
+    def assemble(self, points, all_parts, n_shards):
+        lib, c = self._lib, self.ctx
+        out = np.zeros((len(points), 3))
+        parts = np.ascontiguousarray(all_parts, dtype=np.float64)
+        c.check(c._lib.o3d_estimate_normals_assemble(c.handle, lib.ptr(points), len(points), lib.ptr(parts), n_shards, lib.MEM_HOST,
+                                                     lib.ptr(out)))
+        return out
+
+
+class ShardedNormals:
+    """PointCloud::EstimateNormals (EstimateNormals.cpp:320-351) with the per-point loop split over a process group: every
+    rank builds the grid over the whole cloud, computes the normals of its contiguous range of cell-ordered points, the
+    parts are all-gathered in rank order (one collective of 24 B per point) and scattered to the caller's order on every
+    rank.  Result bit-identical to the single-GPU call."""
+
+    def __init__(self, engine=None, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.engine = engine or HipNormalsEngine()
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device if device is not None else torch.device("cpu")
+
+    def run(self, cloud, search_param):
+        pts = np.ascontiguousarray(cloud.points_, dtype=np.float64)
+        ref = np.ascontiguousarray(cloud.normals_, dtype=np.float64) if cloud.HasNormals() else None
+        part, ng = self.engine.shard(pts, ref, search_param, self.rank, self.world)
+        rows = part.shape[0]  # ceil(ng / world): the same on every rank
+        t = self.torch.from_numpy(np.ascontiguousarray(part)).to(self.device)
+        if self.world > 1:
+            allt = self.torch.zeros((self.world * rows, 3), dtype=t.dtype, device=self.device)
+            if rows > 0:
+                self.dist.all_gather_into_tensor(allt, t, group=self.group)
+            parts = allt.cpu().numpy()
+        else:
+            parts = t.cpu().numpy()
+        cloud.normals_ = self.engine.assemble(pts, parts, self.world)
+        return cloud

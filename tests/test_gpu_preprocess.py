@@ -262,3 +262,31 @@ def test_fpfh_edge_cases(ctx):
         reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamRadius(0.1), ctx=ctx)   # radius search: not on the device path
     one = geometry.PointCloud(sc["target"][:1], normals=nrm[:1])
     assert reg.ComputeFPFHFeature(one, ctx=ctx).data_.shape == (33, 1)
+
+
+@pytest.mark.parametrize("mode", ["knn", "hybrid", "radius"])
+def test_estimate_normals_shards_reassemble_bit_identically(ctx, mode):
+    """o3d_estimate_normals_shard x G + o3d_estimate_normals_assemble (the multi-GPU split, rehearsed on one GPU) must
+    give the bits of the single call, for any number of shards, with non-finite points and an orientation reference."""
+    geometry = _geo()
+    from open3d_amd.sharded import HipNormalsEngine
+    sc = make_scene(100, 9001, cfg_id=61)
+    pts, s = sc["target"].copy(), sc["spacing"]
+    pts[17] = np.nan
+    pts[4000, 1] = np.inf
+    sp = {"knn": geometry.KDTreeSearchParamKNN(20), "hybrid": geometry.KDTreeSearchParamHybrid(4 * s, 30),
+          "radius": geometry.KDTreeSearchParamRadius(2.5 * s)}[mode]
+    ref_n = np.tile([0.0, 0.0, 1.0], (len(pts), 1))
+    for oriented in (None, ref_n):
+        whole = geometry.PointCloud(pts, normals=None if oriented is None else oriented.copy())
+        whole.EstimateNormals(sp, ctx=ctx)
+        eng = HipNormalsEngine(ctx)
+        for G in (1, 2, 3, 8):
+            parts = []
+            for g in range(G):
+                part, ng = eng.shard(pts, oriented, sp, g, G)
+                assert ng == len(pts) - 2 and part.shape[0] == (ng + G - 1) // G
+                parts.append(part)
+            # the last shard's call left the grid in the context: assemble follows directly
+            got = eng.assemble(pts, np.concatenate(parts), G)
+            assert np.array_equal(got, whole.normals_), (mode, G)

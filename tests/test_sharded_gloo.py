@@ -230,3 +230,64 @@ def test_batch_pairs_dealt_over_two_ranks(oracle, tmp_path):
         for w in (1, 2, 8):
             got = sorted(sum((pair_indices(n, w, r) for r in range(w)), []))
             assert got == list(range(n))
+
+
+class OracleNormalsEngine:
+    """Stand-in for HipNormalsEngine: same two methods, the oracle's EstimateNormals, 'cell order' = finite points in
+    index order."""
+
+    def shard(self, points, normals, sp, shard, n_shards):
+        import oracle
+        full = oracle.estimate_normals(points, sp.search_type, sp.knn_, sp.radius_, normals)
+        fin = np.flatnonzero(np.isfinite(points).all(1))
+        ng = len(fin)
+        rows = (ng + n_shards - 1) // n_shards
+        part = np.zeros((rows, 3))
+        mine = fin[shard * rows:(shard + 1) * rows]
+        part[:len(mine)] = full[mine]
+        return part, ng
+
+    def assemble(self, points, all_parts, n_shards):
+        fin = np.flatnonzero(np.isfinite(points).all(1))
+        out = np.tile([0.0, 0.0, 1.0], (len(points), 1))
+        out[fin] = all_parts[:len(fin)]
+        return out
+
+
+def _normals_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from conftest import make_scene
+    from open3d_amd import geometry
+    from open3d_amd.sharded import ShardedNormals
+    import oracle
+    oracle.set_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = make_scene(10, 3001, cfg_id=71)
+    pts = sc["target"].copy()
+    pts[5] = np.nan
+    pc = geometry.PointCloud(pts)
+    ShardedNormals(OracleNormalsEngine(), None, torch.device("cpu")).run(pc, geometry.KDTreeSearchParamHybrid(4 * sc["spacing"], 30))
+    np.save(os.path.join(tmpdir, "nrm%d.npy" % rank), pc.normals_)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_normals_two_ranks(oracle, tmp_path):
+    """EstimateNormals split over two ranks (gloo): one all-gather of the parts, every rank ends with the single-process
+    normals, bit for bit (odd point count: the ranks' parts differ in length, the last one is padded)."""
+    import torch.multiprocessing as mp
+    from conftest import make_scene
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_normals_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sc = make_scene(10, 3001, cfg_id=71)
+    pts = sc["target"].copy()
+    pts[5] = np.nan
+    want = oracle.estimate_normals(pts, oracle.HYBRID, 30, 4 * sc["spacing"])
+    a, b = (np.load(os.path.join(str(tmp_path), "nrm%d.npy" % r)) for r in range(world))
+    assert np.array_equal(a, b) and np.array_equal(a, want)
