@@ -311,6 +311,10 @@ O3D_API int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *s
                                                    double *out_T, int32_t *out_inlier, int64_t *out_n_inlier,
                                                    double *out_fitness, double *out_rmse);
 
+/* Tuning aid, no counterpart in the reference: best-of-reps milliseconds of one copy of `bytes` of pageable host memory to
+ * (to_device = 1) or from the device, through the library's staged path (staged = 1) or plain hipMemcpyAsync. */
+O3D_API int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, int reps, double *out_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <random>
@@ -109,7 +110,7 @@ bool is_identity(const double *T) {
 int to_device(o3d_ctx *ctx, const void *p, size_t bytes, int mem, void **slot_ptr, size_t *slot_cap, const void **out) {
   if (mem == O3D_MEM_DEVICE || p == nullptr || bytes == 0) { *out = p; return O3D_OK; }
   O3D_TRY(o3d_reserve(ctx, slot_ptr, slot_cap, bytes));
-  O3D_HIP(ctx, hipMemcpyAsync(*slot_ptr, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  O3D_HIP(ctx, o3d_h2d(ctx, *slot_ptr, p, bytes));
   *out = *slot_ptr;
   return O3D_OK;
 }
@@ -174,7 +175,7 @@ struct DevBufs {
     void *d = nullptr;
     O3D_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
     owned.push_back(d);
-    if (count) O3D_HIP(ctx, hipMemcpyAsync(d, p, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    if (count) O3D_HIP(ctx, o3d_h2d(ctx, d, p, sizeof(T) * count));
     *out = (const T *)d;
     return O3D_OK;
   }
@@ -240,6 +241,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->sint_sorted) (void)hipFree(ctx->sint_sorted);
   for (hipEvent_t e : ctx->prof_ev)
     if (e) (void)hipEventDestroy(e);
+  o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -371,7 +373,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   hs->with_scaling = with_scaling;
   // fixed origin for the Umeyama moments: centre of the target's bounding box (cuts cancellation, any value is valid)
   for (int d = 0; d < 3; d++) hs->centre[d] = ctx->gp.gmin[d] + 0.5 * ctx->gp.h * (double)(d == 0 ? ctx->gp.nx : (d == 1 ? ctx->gp.ny : ctx->gp.nz));
-  O3D_HIP(ctx, hipMemcpyAsync(ctx->state, hs, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
+  O3D_HIP(ctx, o3d_h2d(ctx, ctx->state, hs, sizeof(IcpState)));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   float ms0 = 0, ms1 = 0;
   (void)hipEventElapsedTime(&ms0, ev[0], ev[1]);
@@ -438,7 +440,7 @@ int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
   O3D_LOCK(ctx);
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "no source loaded");
   DeviceGuard guard(ctx->device);
-  O3D_HIP(ctx, hipMemcpyAsync(host_out, ctx->src_perm, sizeof(uint32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, host_out, ctx->src_perm, sizeof(uint32_t) * (size_t)ctx->n_src));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return O3D_OK;
 }
@@ -507,7 +509,7 @@ int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes) {
   if (!ctx->icp_ready) return o3d_fail(ctx, O3D_ERR_STATE, "o3d_icp_poll before o3d_icp_setup");
   DeviceGuard guard(ctx->device);
   IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
-  O3D_HIP(ctx, hipMemcpyAsync(hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, hs, ctx->state, sizeof(IcpState)));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (out_done) *out_done = hs->done;
   if (out_passes) *out_passes = hs->passes;
@@ -525,11 +527,11 @@ int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, i
       O3D_TRY(o3d_launch_scatter_corr(ctx, out_corr));
     } else {
       O3D_TRY(o3d_launch_scatter_corr(ctx, ctx->corr_out));
-      O3D_HIP(ctx, hipMemcpyAsync(out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, o3d_d2h(ctx, out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src));
     }
   }
   IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
-  O3D_HIP(ctx, hipMemcpyAsync(hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, hs, ctx->state, sizeof(IcpState)));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   O3D_TRY(check_bound_violations(ctx));
   if (out_T) memcpy(out_T, hs->T, sizeof(double) * 16);
@@ -550,7 +552,7 @@ int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows)
   int rows = passes < max_rows ? passes : max_rows;
   if (rows > ctx->log_rows) rows = ctx->log_rows;
   if (rows > 0) {
-    O3D_HIP(ctx, hipMemcpyAsync(host_log, ctx->log, sizeof(double) * O3D_LOG_STRIDE * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, host_log, ctx->log, sizeof(double) * O3D_LOG_STRIDE * (size_t)rows));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (out_rows) *out_rows = rows;
@@ -734,11 +736,11 @@ int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr,
       O3D_TRY(o3d_launch_scatter_corr(ctx, out_corr));
     } else {
       O3D_TRY(o3d_launch_scatter_corr(ctx, ctx->corr_out));
-      O3D_HIP(ctx, hipMemcpyAsync(out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, o3d_d2h(ctx, out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src));
     }
   }
   double *hq = reinterpret_cast<double *>(ctx->pinned);
-  O3D_HIP(ctx, hipMemcpyAsync(hq, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, hq, ctx->sums, sizeof(double) * O3D_NSUMS));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   O3D_TRY(check_bound_violations(ctx));
   const double nc = hq[O3D_SUM_NC];
@@ -775,7 +777,7 @@ static int pairs_common(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, cons
   O3D_TRY(o3d_launch_pairs(ctx, (const double *)d_src, n_src, (const double *)d_tgt, (const double *)d_nrm, n_tgt,
                            (const int32_t *)d_pairs, n_pairs, estimation, with_scaling, ctx->sums, d_bad));
   double *hq = reinterpret_cast<double *>(ctx->pinned);
-  O3D_HIP(ctx, hipMemcpyAsync(hq, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, hq, ctx->sums, sizeof(double) * O3D_NSUMS));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   int bad;
   memcpy(&bad, hq + 24, sizeof bad);
@@ -816,7 +818,7 @@ int o3d_information_matrix(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, c
   DeviceGuard guard(ctx->device);
   O3D_TRY(o3d_launch_info(ctx, ctx->sums));
   double *q = reinterpret_cast<double *>(ctx->pinned);
-  O3D_HIP(ctx, hipMemcpyAsync(q, ctx->sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, q, ctx->sums, sizeof(double) * O3D_NSUMS));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->sums_valid = 0;  // ctx->sums no longer holds the pass sums
   const double sx = q[0], sy = q[1], sz = q[2], xx = q[3], yy = q[4], zz = q[5], xy = q[6], xz = q[7], yz = q[8], n = q[9];
@@ -863,7 +865,7 @@ int o3d_evaluate_hypotheses(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, 
       O3D_TRY(o3d_icp_pass_to(ctx, (double *)d_all + (size_t)k * O3D_NSUMS));
     }
     std::vector<double> h((size_t)n_hyp * O3D_NSUMS);
-    O3D_HIP(ctx, hipMemcpyAsync(h.data(), d_all, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, h.data(), d_all, sizeof(double) * h.size()));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int best = -1;
     double bf = 0.0, br = 0.0;  // RegistrationResult() starts at fitness 0, rmse 0 (Registration.h:112-113)
@@ -991,8 +993,8 @@ int o3d_feature_nearest(o3d_ctx *ctx, const double *src_feature, int64_t n_src, 
   }
   O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, d_q, n_q, d_idx, d_d2));
   if (mem == O3D_MEM_HOST) {
-    O3D_HIP(ctx, hipMemcpyAsync(out_index, d_idx, sizeof(int32_t) * (size_t)n_q, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_d2) O3D_HIP(ctx, hipMemcpyAsync(out_d2, d_d2, sizeof(double) * (size_t)n_q, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, out_index, d_idx, sizeof(int32_t) * (size_t)n_q));
+    if (out_d2) O3D_HIP(ctx, o3d_d2h(ctx, out_d2, d_d2, sizeof(double) * (size_t)n_q));
   }
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return O3D_OK;
@@ -1041,8 +1043,8 @@ int o3d_ransac_hypotheses(o3d_ctx *ctx, const double *src_xyz, const double *src
   a.corres = d_c; a.n_hyp = n_hyp; a.out_T = d_T; a.out_ok = d_ok;
   O3D_TRY(o3d_launch_ransac_hypotheses(ctx, a));
   if (mem == O3D_MEM_HOST) {
-    O3D_HIP(ctx, hipMemcpyAsync(out_T, d_T, sizeof(double) * 16 * (size_t)n_hyp, hipMemcpyDeviceToHost, ctx->stream));
-    O3D_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, sizeof(int32_t) * (size_t)n_hyp, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, out_T, d_T, sizeof(double) * 16 * (size_t)n_hyp));
+    O3D_HIP(ctx, o3d_d2h(ctx, out_ok, d_ok, sizeof(int32_t) * (size_t)n_hyp));
   }
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return O3D_OK;
@@ -1114,7 +1116,7 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
   const bool all_up_front = (double)max_iteration * ransac_n >= 0.5 * (double)n_src;
   if (all_up_front) {
     O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, nullptr, n_src, d_nn, nullptr));
-    O3D_HIP(ctx, hipMemcpyAsync(nn.data(), d_nn, sizeof(int32_t) * (size_t)n_src, hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, nn.data(), d_nn, sizeof(int32_t) * (size_t)n_src));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
 
@@ -1152,20 +1154,20 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
         for (size_t k = 0; k < nid; k++)
           if (nn[(size_t)ids[k]] == -2) { nn[(size_t)ids[k]] = -3; pending.push_back(ids[k]); }
         if (!pending.empty()) {
-          O3D_HIP(ctx, hipMemcpyAsync(d_ids, pending.data(), sizeof(int32_t) * pending.size(), hipMemcpyHostToDevice, ctx->stream));
+          O3D_HIP(ctx, o3d_h2d(ctx, d_ids, pending.data(), sizeof(int32_t) * pending.size()));
           O3D_TRY(o3d_feature_nn_device(ctx, d_sf, n_src, d_tf, n_tgt, dim, d_ids, (int64_t)pending.size(), d_nn, nullptr));
           std::vector<int32_t> got(pending.size());
-          O3D_HIP(ctx, hipMemcpyAsync(got.data(), d_nn, sizeof(int32_t) * pending.size(), hipMemcpyDeviceToHost, ctx->stream));
+          O3D_HIP(ctx, o3d_d2h(ctx, got.data(), d_nn, sizeof(int32_t) * pending.size()));
           O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
           for (size_t k = 0; k < pending.size(); k++) nn[(size_t)pending[k]] = got[k];
         }
       }
       for (size_t k = 0; k < nid; k++) { corres[2 * k] = ids[k]; corres[2 * k + 1] = nn[(size_t)ids[k]]; }  // :243-245
-      O3D_HIP(ctx, hipMemcpyAsync(d_corres, corres.data(), sizeof(int32_t) * 2 * nid, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, o3d_h2d(ctx, d_corres, corres.data(), sizeof(int32_t) * 2 * nid));
       ra.n_hyp = nb;
       O3D_TRY(o3d_launch_ransac_hypotheses(ctx, ra));  // :250-268
-      O3D_HIP(ctx, hipMemcpyAsync(ok.data(), d_ok, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
-      O3D_HIP(ctx, hipMemcpyAsync(Ts.data(), d_T, sizeof(double) * 16 * (size_t)nb, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, o3d_d2h(ctx, ok.data(), d_ok, sizeof(int32_t) * (size_t)nb));
+      O3D_HIP(ctx, o3d_d2h(ctx, Ts.data(), d_T, sizeof(double) * 16 * (size_t)nb));
       O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
       // validation (:269-284) of the hypotheses that passed, in iteration order, until max_validation is reached
       int nv = 0;
@@ -1178,7 +1180,7 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
         nv++;
       }
       if (nv > 0) {
-        O3D_HIP(ctx, hipMemcpyAsync(sums.data(), d_all, sizeof(double) * (size_t)nv * O3D_NSUMS, hipMemcpyDeviceToHost, ctx->stream));
+        O3D_HIP(ctx, o3d_d2h(ctx, sums.data(), d_all, sizeof(double) * (size_t)nv * O3D_NSUMS));
         O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int v = 0; v < nv; v++) {
           const double nc = sums[(size_t)v * O3D_NSUMS + O3D_SUM_NC];
@@ -1272,7 +1274,7 @@ int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, 
   const int32_t *h_corres = corres;
   if (mem == O3D_MEM_DEVICE) {
     hc.resize(2 * (size_t)n_corres);
-    O3D_HIP(ctx, hipMemcpyAsync(hc.data(), corres, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, hc.data(), corres, sizeof(int32_t) * hc.size()));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h_corres = hc.data();
   }
@@ -1297,7 +1299,7 @@ int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, 
   O3D_TRY(b.tmp(ctx, 16 * (size_t)n_hyp, &d_T));
   O3D_TRY(b.tmp(ctx, 2 * (size_t)n_hyp, &d_res));
   O3D_TRY(b.tmp(ctx, (size_t)n_corres, &d_mask));
-  O3D_HIP(ctx, hipMemcpyAsync(d_sets, sets.data(), sizeof(int32_t) * sets.size(), hipMemcpyHostToDevice, ctx->stream));
+  O3D_HIP(ctx, o3d_h2d(ctx, d_sets, sets.data(), sizeof(int32_t) * sets.size()));
   RansacArgs ra;
   fill_ransac_args(ra, d_src, nullptr, n_src, d_tgt, d_tnrm, n_tgt, ransac_n, estimation, with_scaling, -1.0, -1.0, -1.0);
   ra.corres = d_sets; ra.n_hyp = n_hyp; ra.out_T = d_T; ra.out_ok = d_ok;
@@ -1305,8 +1307,8 @@ int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, 
     O3D_TRY(o3d_launch_ransac_hypotheses(ctx, ra));  // :187
     O3D_TRY(o3d_ransac_corr_eval_device(ctx, d_T, n_hyp, d_src, n_src, d_tgt, n_tgt, d_corres, n_corres, max_dist, d_res));  // :188-190
     std::vector<double> res(2 * (size_t)n_hyp), Ts(16 * (size_t)n_hyp);
-    O3D_HIP(ctx, hipMemcpyAsync(res.data(), d_res, sizeof(double) * res.size(), hipMemcpyDeviceToHost, ctx->stream));
-    O3D_HIP(ctx, hipMemcpyAsync(Ts.data(), d_T, sizeof(double) * Ts.size(), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, res.data(), d_res, sizeof(double) * res.size()));
+    O3D_HIP(ctx, o3d_d2h(ctx, Ts.data(), d_T, sizeof(double) * Ts.size()));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int h = 0; h < n_hyp; h++) {  // :191-193, in iteration order
       const double good = res[2 * (size_t)h];
@@ -1321,6 +1323,36 @@ int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *src_xyz, 
   };
   const int st = run();
   (void)hipStreamSynchronize(ctx->stream);
+  return st;
+}
+
+// Tuning aid (not part of the drop-in surface): milliseconds of one host <-> device copy of `bytes` of pageable memory
+// through o3d_h2d / o3d_d2h (staged = 1) or plain hipMemcpyAsync (staged = 0), best of `reps`.
+int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, int reps, double *out_ms) {
+  if (!ctx || !out_ms || bytes == 0) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  void *d = nullptr;
+  O3D_HIP(ctx, hipMalloc(&d, bytes));
+  char *h = (char *)malloc(bytes);
+  if (!h) { (void)hipFree(d); return o3d_fail(ctx, O3D_ERR_OOM, "host allocation"); }
+  memset(h, 1, bytes);
+  double best = 1e30;
+  int st = O3D_OK;
+  for (int r = 0; r < reps + 1 && st == O3D_OK; r++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e;
+    if (staged) e = to_device ? o3d_h2d(ctx, d, h, bytes) : o3d_d2h(ctx, h, d, bytes);
+    else e = hipMemcpyAsync(to_device ? d : (void *)h, to_device ? (const void *)h : d, bytes,
+                            to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = o3d_fail(ctx, O3D_ERR_HIP, "copy bench: %s", hipGetErrorString(e));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (r > 0 && ms < best) best = ms;
+  }
+  *out_ms = best;
+  free(h);
+  (void)hipFree(d);
   return st;
 }
 

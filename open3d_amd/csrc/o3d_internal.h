@@ -113,6 +113,7 @@ struct o3d_ctx {
   void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void *pinned = nullptr;  // 4 KiB pinned host staging
+  void *xfer = nullptr;    // staged-copy state (xfer.hip), created by the first large host <-> device copy
 };
 
 // ---- helpers ----------------------------------------------------------------
@@ -133,6 +134,11 @@ int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...);
 // grow-only device buffer
 int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes);
 int o3d_scratch(o3d_ctx *ctx, int slot, size_t bytes, void **out);
+
+// ---- xfer.hip: copies of caller (pageable) buffers, ordered with ctx->stream -------
+hipError_t o3d_h2d(o3d_ctx *ctx, void *dst, const void *src, size_t bytes);
+hipError_t o3d_d2h(o3d_ctx *ctx, void *dst, const void *src, size_t bytes);
+void o3d_xfer_destroy(o3d_ctx *ctx);
 
 // ---- sort_scan.hip ------------------------------------------------------------
 // Stable LSD radix sort of (key, value) pairs, 8 bits per pass over the low `bits` bits of the key.

@@ -828,7 +828,7 @@ static int count_occupied_cells(o3d_ctx *ctx, int64_t n, int64_t *out) {
   hipLaunchKernelGGL(k_count_heads, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint32_t *)ctx->scratch[1], n,
                      ctx->gp.ncell, (unsigned long long *)cnt);
   unsigned long long *h = (unsigned long long *)ctx->pinned;
-  O3D_HIP(ctx, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+  O3D_HIP(ctx, o3d_d2h(ctx, h, cnt, 8));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = (int64_t)*h;
   return O3D_OK;
@@ -882,11 +882,11 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
   auto run = [&]() -> int {
     if (mem == O3D_MEM_HOST) {
       O3D_HIP(ctx, hipMalloc(&sx, bytes));
-      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, bytes));
       d_xyz = (const double *)sx;
       if (!sharded || has_normals) {
         O3D_HIP(ctx, hipMalloc(&sn, bytes));
-        if (has_normals) O3D_HIP(ctx, hipMemcpyAsync(sn, normals, bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (has_normals) O3D_HIP(ctx, o3d_h2d(ctx, sn, normals, bytes));
         d_nrm = (double *)sn;
       }
     }
@@ -947,9 +947,9 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST) {
       if (sharded) {
-        if (rows > 0) O3D_HIP(ctx, hipMemcpyAsync(out_part, d_out, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+        if (rows > 0) O3D_HIP(ctx, o3d_d2h(ctx, out_part, d_out, sizeof(double) * 3 * (size_t)rows));
       } else {
-        O3D_HIP(ctx, hipMemcpyAsync(normals, d_nrm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        O3D_HIP(ctx, o3d_d2h(ctx, normals, d_nrm, bytes));
       }
     }
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -995,15 +995,15 @@ int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t 
       O3D_HIP(ctx, hipMalloc(&sx, bytes));
       O3D_HIP(ctx, hipMalloc(&sn, bytes));
       O3D_HIP(ctx, hipMalloc(&sp, pbytes));
-      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
-      O3D_HIP(ctx, hipMemcpyAsync(sp, all_parts, sizeof(double) * 3 * (size_t)(rows * n_shards), hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, bytes));
+      O3D_HIP(ctx, o3d_h2d(ctx, sp, all_parts, sizeof(double) * 3 * (size_t)(rows * n_shards)));
       d_xyz = (const double *)sx; d_nrm = (double *)sn; d_parts = (const double *)sp;
     }
     if (ng > 0)
       hipLaunchKernelGGL(k_normals_scatter, dim3(grid_for(ng)), dim3(O3D_BLOCK), 0, ctx->stream, ctx->tgt_sorted, ng, d_parts, d_nrm);
     if (ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);
     O3D_HIP(ctx, hipGetLastError());
-    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(normals, d_nrm, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, o3d_d2h(ctx, normals, d_nrm, bytes));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return O3D_OK;
   };
@@ -1032,16 +1032,16 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
     int32_t *o_vox = out_vox;
     if (mem == O3D_MEM_HOST) {
       O3D_HIP(ctx, hipMalloc(&stage[0], bytes));
-      O3D_HIP(ctx, hipMemcpyAsync(stage[0], xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, o3d_h2d(ctx, stage[0], xyz, bytes));
       d_xyz = (const double *)stage[0];
       if (nrm) {
         O3D_HIP(ctx, hipMalloc(&stage[1], bytes));
-        O3D_HIP(ctx, hipMemcpyAsync(stage[1], nrm, bytes, hipMemcpyHostToDevice, ctx->stream));
+        O3D_HIP(ctx, o3d_h2d(ctx, stage[1], nrm, bytes));
         d_nrm = (const double *)stage[1];
       }
       if (col) {
         O3D_HIP(ctx, hipMalloc(&stage[2], bytes));
-        O3D_HIP(ctx, hipMemcpyAsync(stage[2], col, bytes, hipMemcpyHostToDevice, ctx->stream));
+        O3D_HIP(ctx, o3d_h2d(ctx, stage[2], col, bytes));
         d_col = (const double *)stage[2];
       }
     }
@@ -1086,7 +1086,7 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
     O3D_HIP(ctx, hipMemsetAsync((uint32_t *)head + nf, 0, sizeof(uint32_t), ctx->stream));
     O3D_TRY(o3d_exclusive_scan_u32(ctx, (uint32_t *)head, (uint32_t *)bsum, nf + 1));
     uint32_t *hm = (uint32_t *)ctx->pinned;
-    O3D_HIP(ctx, hipMemcpyAsync(hm, (uint32_t *)head + nf, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, o3d_d2h(ctx, hm, (uint32_t *)head + nf, sizeof(uint32_t)));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t m = (int64_t)*hm;
     // segment starts reuse the tmp-vals buffer (free after the sort)
@@ -1107,10 +1107,10 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST) {
       const size_t ob = sizeof(double) * 3 * (size_t)m;
-      O3D_HIP(ctx, hipMemcpyAsync(out_xyz, o_xyz, ob, hipMemcpyDeviceToHost, ctx->stream));
-      if (nrm) O3D_HIP(ctx, hipMemcpyAsync(out_nrm, o_nrm, ob, hipMemcpyDeviceToHost, ctx->stream));
-      if (col) O3D_HIP(ctx, hipMemcpyAsync(out_col, o_col, ob, hipMemcpyDeviceToHost, ctx->stream));
-      if (out_vox) O3D_HIP(ctx, hipMemcpyAsync(out_vox, o_vox, sizeof(int32_t) * 3 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, o3d_d2h(ctx, out_xyz, o_xyz, ob));
+      if (nrm) O3D_HIP(ctx, o3d_d2h(ctx, out_nrm, o_nrm, ob));
+      if (col) O3D_HIP(ctx, o3d_d2h(ctx, out_col, o_col, ob));
+      if (out_vox) O3D_HIP(ctx, o3d_d2h(ctx, out_vox, o_vox, sizeof(int32_t) * 3 * (size_t)m));
     }
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out_m = m;
@@ -1170,14 +1170,14 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
     if (mem == O3D_MEM_HOST) {
       if (n_cloud > 0) {
         O3D_HIP(ctx, hipMalloc(&sc, sizeof(double) * 3 * (size_t)n_cloud));
-        O3D_HIP(ctx, hipMemcpyAsync(sc, cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud, hipMemcpyHostToDevice, ctx->stream));
+        O3D_HIP(ctx, o3d_h2d(ctx, sc, cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud));
         d_cloud = (const double *)sc;
       }
       if (same) {
         d_q = d_cloud;
       } else {
         O3D_HIP(ctx, hipMalloc(&sq, sizeof(double) * 3 * (size_t)n_q));
-        O3D_HIP(ctx, hipMemcpyAsync(sq, q_xyz, sizeof(double) * 3 * (size_t)n_q, hipMemcpyHostToDevice, ctx->stream));
+        O3D_HIP(ctx, o3d_h2d(ctx, sq, q_xyz, sizeof(double) * 3 * (size_t)n_q));
         d_q = (const double *)sq;
       }
       O3D_HIP(ctx, hipMalloc(&so, out_bytes));
@@ -1206,7 +1206,7 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
                          d_q, n_q, kk, thr, (double *)nullptr, (int32_t *)d_out);
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST)
-      O3D_HIP(ctx, hipMemcpyAsync(mode == 2 ? (void *)out_count : (void *)out, so, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      O3D_HIP(ctx, o3d_d2h(ctx, mode == 2 ? (void *)out_count : (void *)out, so, out_bytes));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return O3D_OK;
   };
@@ -1240,8 +1240,8 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
       O3D_HIP(ctx, hipMalloc(&sx, pbytes));
       O3D_HIP(ctx, hipMalloc(&sn, pbytes));
       O3D_HIP(ctx, hipMalloc(&so, fbytes));
-      O3D_HIP(ctx, hipMemcpyAsync(sx, xyz, pbytes, hipMemcpyHostToDevice, ctx->stream));
-      O3D_HIP(ctx, hipMemcpyAsync(sn, nrm, pbytes, hipMemcpyHostToDevice, ctx->stream));
+      O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, pbytes));
+      O3D_HIP(ctx, o3d_h2d(ctx, sn, nrm, pbytes));
       d_xyz = (const double *)sx; d_nrm = (const double *)sn; d_out = (double *)so;
     }
     O3D_HIP(ctx, hipMalloc(&sp, fbytes));
@@ -1249,7 +1249,7 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
     O3D_HIP(ctx, hipMemsetAsync(d_out, 0, fbytes, ctx->stream));
     const bool knn_mode = search_type == O3D_SEARCH_KNN;
     if (knn < 1 || (!knn_mode && !(radius > 0.0))) {  // no point has a neighbour besides (at most) itself: all zero
-      if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(out_feature, d_out, fbytes, hipMemcpyDeviceToHost, ctx->stream));
+      if (mem == O3D_MEM_HOST) O3D_HIP(ctx, o3d_d2h(ctx, out_feature, d_out, fbytes));
       O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
       return O3D_OK;
     }
@@ -1270,7 +1270,7 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
                          thr, knn_mode ? 1 : 0, d_nrm, (const double *)sp, d_out);
       O3D_HIP(ctx, hipGetLastError());
     }
-    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, hipMemcpyAsync(out_feature, d_out, fbytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (mem == O3D_MEM_HOST) O3D_HIP(ctx, o3d_d2h(ctx, out_feature, d_out, fbytes));
     O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return O3D_OK;
   };

@@ -70,18 +70,22 @@ if "3" in which:  # config 3 pipeline: 10M raw -> VoxelDownSample(2 s) both -> E
     s = sc["spacing"]
     v = 2 * s
     src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
-    t0 = time.perf_counter()
-    sv = src.VoxelDownSample(v, ctx=ctx)
-    tv = tgt.VoxelDownSample(v, ctx=ctx)
-    t1 = time.perf_counter()
-    tv.EstimateNormals(geometry.KDTreeSearchParamHybrid(2 * v, 30), ctx=ctx)
-    t2 = time.perf_counter()
-    res = reg.RegistrationICP(sv, tv, 2 * v, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx)
-    t3 = time.perf_counter()
+    for rep in range(2):  # the second run is reported: the first one creates the context's staging buffers and streams
+        t0 = time.perf_counter()
+        sv = src.VoxelDownSample(v, ctx=ctx)
+        tv = tgt.VoxelDownSample(v, ctx=ctx)
+        t1 = time.perf_counter()
+        tv.EstimateNormals(geometry.KDTreeSearchParamHybrid(2 * v, 30), ctx=ctx)
+        t2 = time.perf_counter()
+        res = reg.RegistrationICP(sv, tv, 2 * v, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=ctx)
+        t3 = time.perf_counter()
+        if rep == 0:
+            first_ms = 1e3 * (t3 - t0)
     print(json.dumps({"config": 3, "what": "10M raw -> VoxelDownSample(2 s) x2 -> EstimateNormals(Hybrid(2 v, 30)) -> P2Plane ICP r = 2 v; "
                                            "host buffers, PCIe included",
                       "voxel_ms_both": 1e3 * (t1 - t0), "n_after": [len(sv.points_), len(tv.points_)], "normals_ms": 1e3 * (t2 - t1),
-                      "icp_ms": 1e3 * (t3 - t2), "iterations": res.iterations_, "fitness": res.fitness_, "total_ms": 1e3 * (t3 - t0)}),
+                      "icp_ms": 1e3 * (t3 - t2), "iterations": res.iterations_, "fitness": res.fitness_, "total_ms": 1e3 * (t3 - t0),
+                      "first_run_total_ms": first_ms}),
           flush=True)
 
 if "5" in which:  # config 5 in part: 64 pairs x 200k, P2Plane, criteria (0, 0, 30)
