@@ -41,6 +41,7 @@ struct Xfer {
   unsigned long generation = 0;
   int running = 0;
   bool quit = false;
+  bool broken = false;  // helper threads could not be started
   int device = 0;
 };
 
@@ -92,8 +93,13 @@ hipError_t xfer_init(o3d_ctx *ctx) {
   }
   ctx->xfer = x;  // o3d_xfer_destroy releases whatever was created
   x->device = ctx->device;
-  if (e == hipSuccess)
-    for (int t = 1; t < kThreads; t++) x->th[t] = std::thread(xfer_worker, x, t);
+  if (e == hipSuccess) {
+    try {
+      for (int t = 1; t < kThreads; t++) x->th[t] = std::thread(xfer_worker, x, t);
+    } catch (...) {  // no thread to be had: the copy falls back to the runtime's path (see staged_copy)
+      x->broken = true;
+    }
+  }
   return e;
 }
 
@@ -102,6 +108,8 @@ hipError_t staged_copy(o3d_ctx *ctx, void *dst, const void *src, size_t bytes, b
   hipError_t e = xfer_init(ctx);
   if (e != hipSuccess) return e;
   Xfer *x = static_cast<Xfer *>(ctx->xfer);
+  if (x->broken)
+    return hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream);
   e = hipEventRecord(x->start, ctx->stream);
   if (e != hipSuccess) return e;
   const size_t nchunks = (bytes + kChunk - 1) / kChunk;
