@@ -130,7 +130,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     (search_ms, second_ms), kern_n = engine.sess.profile_read2()  # second: the accumulation kernel of the f64 path only
-    kern_ms = search_ms + second_ms
+    # single-kernel pass: nothing runs between the second and third event (their distance is event overhead)
+    kern_ms = search_ms if args.search == "f32" else search_ms + second_ms
     if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
