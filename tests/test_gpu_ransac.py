@@ -209,3 +209,31 @@ def test_ransac_based_on_correspondence(ctx, oracle):
         out = reg.RegistrationRANSACBasedOnCorrespondence(ps, pt, kw.get("c", c), kw.get("r", r), None, kw.get("ransac_n", 3),
                                                           reg.RANSACConvergenceCriteria(10, 10), seed=1, ctx=ctx)
         assert out.fitness_ == 0.0 and np.array_equal(out.transformation_, np.eye(4)) and len(out.correspondence_set_) == 0
+
+
+def test_ransac_argument_errors(ctx):
+    """Bad arguments fail loudly with a status, never silently: dimensions beyond the device path, mismatching counts,
+    estimations / checkers without a device path."""
+    from open3d_amd import geometry, _lib
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(200, 200, cfg_id=45)
+    ps, pt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    f33 = reg.Feature(np.zeros((33, 200)))
+    with pytest.raises(_lib.O3DError):   # 129-dimensional features: beyond the LDS-resident generic path
+        reg.FeatureNearest(reg.Feature(np.zeros((129, 10))), reg.Feature(np.zeros((129, 10))), ctx=ctx)
+    with pytest.raises(_lib.O3DError):   # feature count != point count
+        reg.RegistrationRANSACBasedOnFeatureMatching(ps, pt, reg.Feature(np.zeros((33, 199))), f33, 0.1, seed=1, ctx=ctx)
+    with pytest.raises(_lib.O3DError):   # dimensions differ
+        reg.RegistrationRANSACBasedOnFeatureMatching(ps, pt, reg.Feature(np.zeros((32, 200))), f33, 0.1, seed=1, ctx=ctx)
+
+    class MyChecker:
+        require_pointcloud_alignment_ = False
+
+    with pytest.raises(_lib.O3DError):   # a user-defined checker has no device path
+        reg.RegistrationRANSACBasedOnFeatureMatching(ps, pt, f33, f33, 0.1, None, 4, [MyChecker()], seed=1, ctx=ctx)
+    # several checkers of one kind combine into the strictest
+    edge, dist, ang = reg._checker_thresholds([reg.CorrespondenceCheckerBasedOnEdgeLength(0.8), reg.CorrespondenceCheckerBasedOnEdgeLength(0.9),
+                                               reg.CorrespondenceCheckerBasedOnDistance(0.3), reg.CorrespondenceCheckerBasedOnDistance(0.2)])
+    assert (edge, dist, ang) == (0.9, 0.2, -1.0)
+    # the context is still usable
+    assert reg.EvaluateRegistration(ps, pt, 3 * sc["spacing"], ctx=ctx).fitness_ > 0
