@@ -315,6 +315,10 @@ O3D_API int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *s
  * (to_device = 1) or from the device, through the library's staged path (staged = 1) or plain hipMemcpyAsync. */
 O3D_API int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, int reps, double *out_ms);
 
+/* Self-check of the library's host <-> device copy path, no counterpart in the reference: pattern-filled buffers of `bytes`
+ * go up and down back to back, `rounds` times; *out_mismatches = 8-byte words that came back different (must be 0). */
+O3D_API int o3d_debug_copy_check(o3d_ctx *ctx, size_t bytes, int rounds, int64_t *out_mismatches);
+
 #ifdef __cplusplus
 }
 #endif

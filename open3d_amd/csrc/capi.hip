@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -1353,6 +1354,46 @@ int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, 
   *out_ms = best;
   free(h);
   (void)hipFree(d);
+  return st;
+}
+
+// Self-check of the staged copy path (xfer.hip): two pattern-filled pageable buffers go up back to back and come down
+// back to back, `rounds` times; *out_mismatches = number of 8-byte words that came back different.
+int o3d_debug_copy_check(o3d_ctx *ctx, size_t bytes, int rounds, int64_t *out_mismatches) {
+  if (!ctx || !out_mismatches || bytes < 16) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  const size_t nw = bytes / 8;
+  void *da = nullptr, *db = nullptr;
+  O3D_HIP(ctx, hipMalloc(&da, nw * 8));
+  hipError_t e0 = hipMalloc(&db, nw * 8);
+  std::vector<uint64_t> a, b, a2, b2;
+  int st = O3D_OK;
+  int64_t bad = 0;
+  try {
+    a.resize(nw); b.resize(nw); a2.resize(nw); b2.resize(nw);
+  } catch (...) {
+    st = o3d_fail(ctx, O3D_ERR_OOM, "host allocation");
+  }
+  if (e0 != hipSuccess) st = o3d_fail(ctx, O3D_ERR_OOM, "device allocation");
+  for (int r = 0; r < rounds && st == O3D_OK; r++) {
+    for (size_t k = 0; k < nw; k++) {
+      a[k] = (k * 0x9E3779B97F4A7C15ull) ^ (uint64_t)(2 * r + 1);
+      b[k] = ~a[k] + k;
+    }
+    std::fill(a2.begin(), a2.end(), 0);
+    std::fill(b2.begin(), b2.end(), 0);
+    hipError_t e = o3d_h2d(ctx, da, a.data(), nw * 8);
+    if (e == hipSuccess) e = o3d_h2d(ctx, db, b.data(), nw * 8);
+    if (e == hipSuccess) e = o3d_d2h(ctx, a2.data(), da, nw * 8);
+    if (e == hipSuccess) e = o3d_d2h(ctx, b2.data(), db, nw * 8);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { st = o3d_fail(ctx, O3D_ERR_HIP, "copy check: %s", hipGetErrorString(e)); break; }
+    for (size_t k = 0; k < nw; k++) bad += (a2[k] != a[k]) + (b2[k] != b[k]);
+  }
+  *out_mismatches = bad;
+  if (da) (void)hipFree(da);
+  if (db) (void)hipFree(db);
   return st;
 }
 

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
 // the block (d2 <= 12 h^2 is irrelevant beyond ~h^2).  kF32Err = 4e-6 (x h^2) is used as the bound e: "decisive" means
 // second - best > 2e and |best - thr| > e; runs are pruned only when their face distance exceeds best + 4e.
 constexpr float kF32Err = 4e-6f;
-constexpr float kSeedMax = 0.5f;   // a seed farther than sqrt(kSeedMax) cells prunes worse than the centre-cell phase
+constexpr float kSeedMax = 0.9f;   // a seed farther than sqrt(kSeedMax) cells prunes worse than the centre-cell phase
 constexpr int kMaxRuns = 10;  // left cell, right cell, eight neighbouring rows
 
 // Four consecutive cell-table entries in one 16-byte load (the table is only 4-byte aligned at an arbitrary cell:

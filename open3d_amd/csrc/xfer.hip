@@ -124,15 +124,17 @@ hipError_t staged_copy(o3d_ctx *ctx, void *dst, const void *src, size_t bytes, b
       const int b = (int)(round & 1);
       const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
       if (to_device) {
-        if (round >= 2) r = hipEventSynchronize(x->ev[t][b]);  // the DMA that last read this pinned buffer
+        // the DMA that last used this pinned buffer -- in this copy or, for the first two rounds, in the previous one,
+        // which returned with its last DMAs still in flight (an event never recorded reads as complete)
+        r = hipEventSynchronize(x->ev[t][b]);
         if (r != hipSuccess) break;
         memcpy(x->pinned[t][b], (const char *)src + off, len);
         r = hipMemcpyAsync((char *)dst + off, x->pinned[t][b], len, hipMemcpyHostToDevice, x->s[t]);
         if (r == hipSuccess) r = hipEventRecord(x->ev[t][b], x->s[t]);
       } else {
+        r = hipEventSynchronize(x->ev[t][b]);  // this buffer's last DMA, of this copy or of the previous one
+        if (r != hipSuccess) break;
         if (pend[b]) {  // drain the chunk that used this buffer two rounds ago
-          r = hipEventSynchronize(x->ev[t][b]);
-          if (r != hipSuccess) break;
           memcpy((char *)dst + pend_off[b], x->pinned[t][b], pend_len[b]);
           pend[b] = false;
         }

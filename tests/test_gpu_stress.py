@@ -171,3 +171,14 @@ def test_seeded_search_walk_on_lattice_with_ties(ctx, oracle):
             assert np.array_equal(got.corr_, corr), "pass %d (tile search %s)" % (k, use_tile)
             assert got.fitness_ == fit and rel_err(got.inlier_rmse_, rmse) < 1e-12 if nc else got.fitness_ == 0.0
     ctx.debug_set(use_tile_search=True)
+
+
+def test_staged_copies_back_to_back(ctx):
+    """xfer.hip: large copies of caller buffers are staged through pinned double buffers by helper threads.  Copies that
+    follow each other directly (source then target of one call) must not disturb one another: a copy returns with its last
+    DMAs still in flight, and the next one reuses the same pinned buffers."""
+    import ctypes as C
+    for mb in (13, 33, 100, 250):       # below / above the staging thresholds, odd sizes
+        bad = C.c_int64(-1)
+        ctx.check(ctx._lib.o3d_debug_copy_check(ctx.handle, (mb << 20) + 24, 3, C.byref(bad)))
+        assert bad.value == 0, "%d MiB: %d words differ" % (mb, bad.value)
