@@ -118,12 +118,15 @@ def test_headline_size_10m_properties(ctx, oracle):
 def test_bench_exchange_path_under_torchrun_one_rank():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, RCCL process group), rehearsed with one rank on
     the one GPU of the box: pass -> all-gather of the 32 sums over RCCL -> solve must give the numbers of the unsharded loop."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:   # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     common = ["--gpus", "1", "--points", "200000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(root, "bench.py")] + common + ["--force-exchange"],
+                        "--master-port", str(port), os.path.join(root, "bench.py")] + common + ["--force-exchange"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert a.returncode == 0, a.stderr[-2000:]
     b = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=300, env=env, cwd=root)
