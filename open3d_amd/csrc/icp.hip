@@ -1029,9 +1029,10 @@ __device__ void ldlt_solve6(const double *A, const double *b, double *x, SolveWo
 }
 
 __device__ void vec6_to_mat4(const double *v, double *T) {
-  const double sx = sin(v[0]), cx = cos(v[0]);
-  const double sy = sin(v[1]), cy = cos(v[1]);
-  const double sz = sin(v[2]), cz = cos(v[2]);
+  double sx, cx, sy, cy, sz, cz;  // one argument reduction per angle
+  sincos(v[0], &sx, &cx);
+  sincos(v[1], &sy, &cy);
+  sincos(v[2], &sz, &cz);
   mat4_identity(T);
   TM(T, 0, 0) = cy * cz;  TM(T, 0, 1) = sx * sy * cz - cx * sz;  TM(T, 0, 2) = cx * sy * cz + sx * sz;
   TM(T, 1, 0) = cy * sz;  TM(T, 1, 1) = sx * sy * sz + cx * cz;  TM(T, 1, 2) = cx * sy * sz - sx * cz;
