@@ -224,3 +224,31 @@ def test_stepwise_sharded_api_on_one_gpu(ctx, oracle):
     assert rel_err(res[0].fitness_, ref.fitness) < TOL and rel_err(res[0].inlier_rmse_, ref.inlier_rmse) < TOL
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_point_to_plane_on_an_exact_plane_zero_pivots(ctx, oracle):
+    """A target lying exactly in z = 0 with normals (0, 0, 1): three columns of J are exactly zero, JTJ has exact zero
+    rows, and the pivoted LDLT (Eigen semantics, utility/Eigen.cpp:85) meets zero pivots -- those components of the update
+    must come out as zero, on the device as in the oracle, every iteration."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    rng = np.random.default_rng(5)
+    tgt = np.zeros((4000, 3))
+    tgt[:, :2] = rng.random((4000, 2)) * 4.0
+    nrm = np.tile([0.0, 0.0, 1.0], (len(tgt), 1))
+    src = np.zeros((3000, 3))
+    src[:, :2] = 0.5 + rng.random((3000, 2)) * 3.0
+    src[:, 2] = 0.01 + 0.02 * (src[:, 0] - 2.0)        # tilted and lifted: only z, rot-x, rot-y are observable
+    r = 0.2
+    crit = reg.ICPConvergenceCriteria(0.0, 0.0, 5)
+    got = reg.RegistrationICP(geometry.PointCloud(src), geometry.PointCloud(tgt, normals=nrm), r, np.eye(4),
+                              reg.TransformationEstimationPointToPlane(), crit, ctx=ctx)
+    ref = oracle.registration_icp(src, tgt, r, None, 2, nrm, rel_fitness=0.0, rel_rmse=0.0, max_iter=5)
+    assert np.all(np.isfinite(got.transformation_))
+    assert np.array_equal(got.corr_, ref.corr)
+    assert rel_err(got.transformation_, ref.transformation) < 1e-6
+    assert got.fitness_ == ref.fitness and rel_err(got.inlier_rmse_, ref.inlier_rmse) < 1e-6
+    # the unobservable rotation about z stays untouched (zero pivot -> zero component)
+    T = got.transformation_
+    assert abs(T[1, 0]) < 1e-12 and abs(T[0, 1]) < 1e-12
