@@ -971,62 +971,113 @@ __device__ void mat4_mul(const double *A, const double *B, double *C) {
 }
 
 // x = A^-1 b by LDL^T with symmetric pivoting on the largest |diagonal| (Eigen::LDLT semantics, utility/Eigen.cpp:85):
-// lower triangle only, zero pivot -> zero component.
-// The pivoting indexes M, y and tr dynamically: they live in the caller's LDS workspace (private arrays would go to scratch
-// memory, a microsecond per dependent access).
-struct SolveWork {
-  double M[36], y[6], temp[6];
-  int tr[6];
-};
-__device__ void ldlt_solve6(const double *A, const double *b, double *x, SolveWork &wk) {
-  const int n = 6;
-  double *M = wk.M, *y = wk.y, *temp = wk.temp;
-  int *tr = wk.tr;
-  for (int i = 0; i < 36; i++) M[i] = A[i];
-#define MM(i, j) M[(i) * 6 + (j)]
-  for (int k = 0; k < n; k++) {
-    int p = k;
-    double big = fabs(MM(k, k));
-    for (int i = k + 1; i < n; i++)
-      if (fabs(MM(i, i)) > big) { big = fabs(MM(i, i)); p = i; }
-    tr[k] = p;
-    if (p != k) {
-      for (int j = 0; j < k; j++) { double t = MM(k, j); MM(k, j) = MM(p, j); MM(p, j) = t; }
-      for (int i = p + 1; i < n; i++) { double t = MM(i, k); MM(i, k) = MM(i, p); MM(i, p) = t; }
-      for (int i = k + 1; i < p; i++) { double t = MM(i, k); MM(i, k) = MM(p, i); MM(p, i) = t; }
-      double t = MM(k, k); MM(k, k) = MM(p, p); MM(p, p) = t;
-    }
-    if (k > 0) {
-      for (int j = 0; j < k; j++) temp[j] = MM(j, j) * MM(k, j);
-      double s = 0;
-      for (int j = 0; j < k; j++) s += MM(k, j) * temp[j];
-      MM(k, k) -= s;
-      for (int i = k + 1; i < n; i++) {
-        double a = 0;
-        for (int j = 0; j < k; j++) a += MM(i, j) * temp[j];
-        MM(i, k) -= a;
-      }
-    }
-    const double akk = MM(k, k);
-    if (fabs(akk) > 0)
-      for (int i = k + 1; i < n; i++) MM(i, k) /= akk;
+// lower triangle only, zero pivot -> zero component.  Everything lives in registers: the step index K is a template
+// parameter and the pivot row P, the one dynamic index, is turned into a static one by a switch over its few possible
+// values (arrays indexed dynamically would go to scratch memory, a microsecond per dependent access on the one lane that
+// runs the estimate; an earlier version kept them in LDS).
+#define MR(i, j) M[(i) * 6 + (j)]
+template <int K, int P>
+__device__ __forceinline__ void ldlt_swap(double (&M)[36]) {
+  double t;
+#pragma unroll
+  for (int j = 0; j < K; j++) { t = MR(K, j); MR(K, j) = MR(P, j); MR(P, j) = t; }
+#pragma unroll
+  for (int i = P + 1; i < 6; i++) { t = MR(i, K); MR(i, K) = MR(i, P); MR(i, P) = t; }
+#pragma unroll
+  for (int i = K + 1; i < P; i++) { t = MR(i, K); MR(i, K) = MR(P, i); MR(P, i) = t; }
+  t = MR(K, K); MR(K, K) = MR(P, P); MR(P, P) = t;
+}
+template <int K>
+__device__ __forceinline__ void ldlt_swap_dyn(double (&M)[36], int p) {
+  switch (p) {
+    case 1: if constexpr (K < 1) ldlt_swap<K, 1>(M); break;
+    case 2: if constexpr (K < 2) ldlt_swap<K, 2>(M); break;
+    case 3: if constexpr (K < 3) ldlt_swap<K, 3>(M); break;
+    case 4: if constexpr (K < 4) ldlt_swap<K, 4>(M); break;
+    case 5: if constexpr (K < 5) ldlt_swap<K, 5>(M); break;
+    default: break;
   }
-  for (int i = 0; i < n; i++) y[i] = b[i];
-  for (int k = 0; k < n; k++)
-    if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j < i; j++) y[i] -= MM(i, j) * y[j];
-  for (int i = 0; i < n; i++) {
-    if (fabs(MM(i, i)) > 2.2250738585072014e-308) y[i] /= MM(i, i);
+}
+template <int K>
+__device__ __forceinline__ void vec_swap_dyn(double (&y)[6], int p) {
+  double t;
+  switch (p) {
+    case 1: if constexpr (K < 1) { t = y[K]; y[K] = y[1]; y[1] = t; } break;
+    case 2: if constexpr (K < 2) { t = y[K]; y[K] = y[2]; y[2] = t; } break;
+    case 3: if constexpr (K < 3) { t = y[K]; y[K] = y[3]; y[3] = t; } break;
+    case 4: if constexpr (K < 4) { t = y[K]; y[K] = y[4]; y[4] = t; } break;
+    case 5: if constexpr (K < 5) { t = y[K]; y[K] = y[5]; y[5] = t; } break;
+    default: break;
+  }
+}
+template <int K>
+__device__ __forceinline__ void ldlt_step(double (&M)[36], int (&tr)[6]) {
+  int p = K;
+  double big = fabs(MR(K, K));
+#pragma unroll
+  for (int i = K + 1; i < 6; i++)
+    if (fabs(MR(i, i)) > big) { big = fabs(MR(i, i)); p = i; }
+  tr[K] = p;
+  if (p != K) ldlt_swap_dyn<K>(M, p);
+  if constexpr (K > 0) {
+    double temp[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) temp[j] = MR(j, j) * MR(K, j);
+    double sdot = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) sdot += MR(K, j) * temp[j];
+    MR(K, K) -= sdot;
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) {
+      double a = 0;
+#pragma unroll
+      for (int j = 0; j < K; j++) a += MR(i, j) * temp[j];
+      MR(i, K) -= a;
+    }
+  }
+  const double akk = MR(K, K);
+  if (fabs(akk) > 0) {
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) MR(i, K) /= akk;
+  }
+}
+__device__ void ldlt_solve6(const double *A, const double *b, double *x) {
+  double M[36];
+  int tr[6];
+#pragma unroll
+  for (int i = 0; i < 36; i++) M[i] = A[i];
+  ldlt_step<0>(M, tr); ldlt_step<1>(M, tr); ldlt_step<2>(M, tr);
+  ldlt_step<3>(M, tr); ldlt_step<4>(M, tr); ldlt_step<5>(M, tr);
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] = b[i];
+  if (tr[0] != 0) vec_swap_dyn<0>(y, tr[0]);
+  if (tr[1] != 1) vec_swap_dyn<1>(y, tr[1]);
+  if (tr[2] != 2) vec_swap_dyn<2>(y, tr[2]);
+  if (tr[3] != 3) vec_swap_dyn<3>(y, tr[3]);
+  if (tr[4] != 4) vec_swap_dyn<4>(y, tr[4]);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) y[i] -= MR(i, j) * y[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    if (fabs(MR(i, i)) > 2.2250738585072014e-308) y[i] /= MR(i, i);
     else y[i] = 0;
   }
-  for (int i = n - 1; i >= 0; i--)
-    for (int j = i + 1; j < n; j++) y[i] -= MM(j, i) * y[j];
-  for (int k = n - 1; k >= 0; k--)
-    if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
-  for (int i = 0; i < n; i++) x[i] = y[i];
-#undef MM
+#pragma unroll
+  for (int i = 5; i >= 0; i--)
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) y[i] -= MR(j, i) * y[j];
+  if (tr[4] != 4) vec_swap_dyn<4>(y, tr[4]);
+  if (tr[3] != 3) vec_swap_dyn<3>(y, tr[3]);
+  if (tr[2] != 2) vec_swap_dyn<2>(y, tr[2]);
+  if (tr[1] != 1) vec_swap_dyn<1>(y, tr[1]);
+  if (tr[0] != 0) vec_swap_dyn<0>(y, tr[0]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = y[i];
 }
+#undef MR
 
 __device__ void vec6_to_mat4(const double *v, double *T) {
   double sx, cx, sy, cy, sz, cz;  // one argument reduction per angle
@@ -1152,8 +1203,7 @@ __device__ void umeyama_from_sums(const double *q, const double *centre, int wit
 }
 
 // One lane: everything between two passes of Registration.cpp:155-166.
-__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows,
-                           SolveWork &wk) {
+__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
   if (nc > 0.0) {  // Registration.cpp:82-89
@@ -1186,7 +1236,7 @@ __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_n
         for (int a = 0; a < 6; a++)
           for (int c = a; c < 6; c++) { A[a * 6 + c] = q[k]; A[c * 6 + a] = q[k]; k++; }
         for (int a = 0; a < 6; a++) b[a] = -q[21 + a];
-        ldlt_solve6(A, b, x, wk);
+        ldlt_solve6(A, b, x);
         vec6_to_mat4(x, upd);
       }
     } else {
@@ -1211,7 +1261,6 @@ __global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict_
   if (blockIdx.x != 0) return;
   if (st->done) return;
   __shared__ IcpState ls;
-  __shared__ SolveWork wk;
   __shared__ double q[O3D_NSUMS];
   state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(st));
   for (int k = threadIdx.x; k < O3D_NSUMS; k += blockDim.x) {
@@ -1220,7 +1269,7 @@ __global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict_
     q[k] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) solve_body(&ls, q, has_normals, log, log_rows, wk);
+  if (threadIdx.x == 0) solve_body(&ls, q, has_normals, log, log_rows);
   __syncthreads();
   state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
 }
@@ -1232,11 +1281,10 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize_solve(const do
   if (st->done) return;
   __shared__ double s[32][O3D_NSUMS];
   __shared__ IcpState ls;
-  __shared__ SolveWork wk;
   state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(st));
   finalize_sums(partials, nparts, s);
   if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
-  if (threadIdx.x == 0) solve_body(&ls, s[0], has_normals, log, log_rows, wk);
+  if (threadIdx.x == 0) solve_body(&ls, s[0], has_normals, log, log_rows);
   __syncthreads();
   state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
 }
@@ -1338,7 +1386,6 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_pairs_accumulate(PairArgs a) {
 __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, int nparts, int estimation, int with_scaling,
                                                                      double *__restrict__ out) {
   __shared__ double s[32][O3D_NSUMS];
-  __shared__ SolveWork wk;
   finalize_sums(a.partials, nparts, s);
   if (threadIdx.x != 0) return;
   double q[O3D_NSUMS];
@@ -1356,7 +1403,7 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, 
         for (int r = 0; r < 6; r++)
           for (int c = r; c < 6; c++) { A[r * 6 + c] = q[k]; A[c * 6 + r] = q[k]; k++; }
         for (int r = 0; r < 6; r++) b[r] = -q[21 + r];
-        ldlt_solve6(A, b, x, wk);
+        ldlt_solve6(A, b, x);
         vec6_to_mat4(x, T);
       }
     } else {
@@ -1421,12 +1468,11 @@ __global__ __launch_bounds__(O3D_WAVE) void k_ransac_hypotheses(RansacArgs a) {
     if (q[O3D_SUM_NC] > 0.0) {
       if (plane) {
         double A[36], bb[6], x[6];
-        SolveWork wk;
         int k = 0;
         for (int r = 0; r < 6; r++)
           for (int cc = r; cc < 6; cc++) { A[r * 6 + cc] = q[k]; A[cc * 6 + r] = q[k]; k++; }
         for (int r = 0; r < 6; r++) bb[r] = -q[21 + r];
-        ldlt_solve6(A, bb, x, wk);
+        ldlt_solve6(A, bb, x);
         vec6_to_mat4(x, T);
       } else {
         umeyama_from_sums(q, c0, a.with_scaling, T);
