@@ -1203,6 +1203,23 @@ __device__ void umeyama_from_sums(const double *q, const double *centre, int wit
 }
 
 // One lane: everything between two passes of Registration.cpp:155-166.
+// One row of the per-pass history, entry e by lane e (52 lanes in parallel instead of 52 stores on the solving lane):
+// {fitness, rmse, n_corr, sum d2, T before this pass's update (16), the 32 sums}.  Reads the state BEFORE solve_body
+// changes it: the callers put a workgroup barrier between the two.
+__device__ __forceinline__ void write_log_row(const IcpState *st, const double *q, double *__restrict__ log, int log_rows, int e) {
+  const int pass = st->passes;
+  if (!log || pass >= log_rows || e >= O3D_LOG_STRIDE) return;
+  const double nc = q[O3D_SUM_NC];
+  double v;
+  if (e == 0) v = nc > 0.0 ? nc / st->n_src_global : 0.0;
+  else if (e == 1) v = nc > 0.0 ? sqrt(q[O3D_SUM_D2] / nc) : 0.0;
+  else if (e == 2) v = nc;
+  else if (e == 3) v = q[O3D_SUM_D2];
+  else if (e < 20) v = st->T[e - 4];
+  else v = q[e - 20];
+  log[(size_t)pass * O3D_LOG_STRIDE + e] = v;
+}
+
 __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
@@ -1214,12 +1231,6 @@ __device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_n
   const double pf = st->fitness, pr = st->rmse;
   st->fitness = fit; st->rmse = rmse; st->n_corr = nc; st->sum_d2 = q[O3D_SUM_D2];
   st->passes = pass + 1;
-  if (log && pass < log_rows) {
-    double *L = log + (size_t)pass * O3D_LOG_STRIDE;
-    L[0] = fit; L[1] = rmse; L[2] = nc; L[3] = q[O3D_SUM_D2];
-    for (int i = 0; i < 16; i++) L[4 + i] = st->T[i];
-    for (int i = 0; i < O3D_NSUMS; i++) L[20 + i] = q[i];
-  }
   if (pass >= 1) {
     st->iters = pass;
     if (fabs(pf - fit) < st->rel_fitness && fabs(pr - rmse) < st->rel_rmse) { st->done = 1; return; }  // :162-165
@@ -1269,6 +1280,8 @@ __global__ void k_icp_solve(IcpState *__restrict__ st, const double *__restrict_
     q[k] = v;
   }
   __syncthreads();
+  write_log_row(&ls, q, log, log_rows, threadIdx.x);
+  __syncthreads();
   if (threadIdx.x == 0) solve_body(&ls, q, has_normals, log, log_rows);
   __syncthreads();
   state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
@@ -1284,6 +1297,8 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize_solve(const do
   state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(st));
   finalize_sums(partials, nparts, s);
   if (threadIdx.x < O3D_NSUMS) sums[threadIdx.x] = s[0][threadIdx.x];
+  if (threadIdx.x >= O3D_WAVE && threadIdx.x < 2 * O3D_WAVE) write_log_row(&ls, s[0], log, log_rows, threadIdx.x - O3D_WAVE);
+  __syncthreads();
   if (threadIdx.x == 0) solve_body(&ls, s[0], has_normals, log, log_rows);
   __syncthreads();
   state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
