@@ -114,8 +114,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_bounds_final(const Bounds6 *__res
 // Non-finite points can never be a nearest neighbour (d2 is NaN or inf): they get the sentinel key ncell and
 // sort behind every real cell.
 __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                            uint32_t *__restrict__ cell_count) {
+                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     uint32_t key = gp.ncell;
@@ -124,10 +123,94 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restr
       int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
       int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
       key = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)(cx + 1);
-      atomicAdd(&cell_count[key], 1u);
     }
     keys[i] = key;
     vals[i] = (uint32_t)i;
+  }
+}
+
+// K1b: the dense prefix table from the SORTED keys: cell_start[k] = number of keys < k, for every k in [0, ntab).
+// One workgroup per kCtCells consecutive cells: the range of sorted keys that falls into them is found by a 64-ary search
+// (one wavefront, 64 probes per step), counted in LDS, scanned in the workgroup and written out once, coalesced -- the
+// table is written exactly once and never read (the earlier version cleared it, built a histogram with one global atomic
+// per point on a table far larger than any cache, and ran a three-kernel scan over all of it).
+constexpr int kCtCells = 8192;
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ keys, uint32_t n, uint64_t target, int lane) {
+  uint32_t lo = 0, hi = n;
+  while (hi > lo) {
+    const uint32_t step = (hi - lo + 63u) / 64u;
+    const uint64_t idx = (uint64_t)lo + (uint64_t)lane * step;
+    const bool pred = idx < hi && (uint64_t)keys[idx] < target;
+    const int k = __popcll(__ballot(pred));  // the keys are sorted: pred holds for lanes 0 .. k - 1
+    if (k == 0) { hi = lo; break; }
+    const uint32_t nlo = lo + (uint32_t)(k - 1) * step + 1u;
+    const uint64_t nhi = (uint64_t)lo + (uint64_t)k * step;
+    hi = nhi < hi ? (uint32_t)nhi : hi;
+    lo = nlo;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ cell_start,
+                                                           uint64_t ntab) {
+  __shared__ __align__(16) uint32_t cnt[kCtCells];
+  __shared__ uint32_t bounds[2];
+  __shared__ uint32_t wsum[O3D_BLOCK / O3D_WAVE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t c0 = (uint64_t)blockIdx.x * kCtCells;
+  if (wave < 2) {  // the two ends of the key range, one wavefront each
+    const uint32_t a = wave_lower_bound(keys, n, c0 + (uint64_t)wave * kCtCells, lane);
+    if (lane == 0) bounds[wave] = a;
+  }
+  constexpr int kQuads = kCtCells / (4 * O3D_BLOCK);  // uint4 stores per thread
+  uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
+#pragma unroll
+  for (int q = 0; q < kQuads; q++) cnt4[q * O3D_BLOCK + tid] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const uint32_t p0 = bounds[0], p1 = bounds[1];
+  if (p1 > p0) {  // (most workgroups of a sparse table own no point and skip this)
+    for (uint32_t p = p0 + tid; p < p1; p += O3D_BLOCK) atomicAdd(&cnt[(uint32_t)((uint64_t)keys[p] - c0)], 1u);
+    __syncthreads();
+    // exclusive scan in place: each wavefront over its own quarter, 256 cells (one uint4 per lane) at a time
+    constexpr int kWaveCells = kCtCells / (O3D_BLOCK / O3D_WAVE);
+    uint32_t carry = 0;
+#pragma unroll 2
+    for (int it = 0; it < kWaveCells / (4 * O3D_WAVE); it++) {
+      const int qi = (wave * kWaveCells) / 4 + it * O3D_WAVE + lane;
+      const uint4 v = cnt4[qi];
+      const uint32_t sum = v.x + v.y + v.z + v.w;
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < O3D_WAVE; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, O3D_WAVE);
+        if (lane >= d) incl += o;
+      }
+      const uint32_t e = carry + incl - sum;
+      cnt4[qi] = make_uint4(e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z);
+      carry += __shfl(incl, O3D_WAVE - 1, O3D_WAVE);
+    }
+    if (lane == 0) wsum[wave] = carry;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < kQuads; q++) {
+    const int qi = q * O3D_BLOCK + tid;
+    uint4 v = make_uint4(p0, p0, p0, p0);
+    if (p1 > p0) {
+      constexpr int kWaveQuads = kCtCells / (O3D_BLOCK / O3D_WAVE) / 4;
+      uint32_t base = p0;
+      for (int w = 0; w < qi / kWaveQuads; w++) base += wsum[w];
+      const uint4 e = cnt4[qi];
+      v = make_uint4(base + e.x, base + e.y, base + e.z, base + e.w);
+    }
+    const uint64_t c = c0 + 4ull * (uint64_t)qi;
+    if (c + 3 < ntab) {
+      *reinterpret_cast<uint4 *>(cell_start + c) = v;
+    } else {
+      if (c < ntab) cell_start[c] = v.x;
+      if (c + 1 < ntab) cell_start[c + 1] = v.y;
+      if (c + 2 < ntab) cell_start[c + 2] = v.z;
+    }
   }
 }
 
@@ -308,8 +391,11 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   // dense table: ncell + 1 prefix entries (+1 sentinel bucket for non-finite points), padded for uint4 access
   const size_t ntab = (size_t)gp.ncell + 2;
   O3D_TRY(o3d_reserve(ctx, (void **)&ctx->cell_start, &ctx->cap_cells, sizeof(uint32_t) * (ntab + 8)));
-  O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (ntab + 8), ctx->stream));
-  if (n <= 0) return O3D_OK;
+  if (n <= 0) {
+    O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (ntab + 8), ctx->stream));
+    return O3D_OK;
+  }
+  O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start + ntab, 0, sizeof(uint32_t) * 8, ctx->stream));  // the padding entries
 
   O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
   // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
@@ -319,20 +405,20 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
 
   const size_t ntiles = o3d_sort_num_tiles(n);
   const size_t nh = 256 * ntiles;
-  void *keys, *vals, *tkeys, *tvals, *hist, *bsum;
+  void *keys, *vals, *tkeys, *tvals, *hist;
   O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
   O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
   O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
   O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
   O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
-  O3D_TRY(o3d_scratch(ctx, 6, sizeof(uint32_t) * (o3d_scan_num_blocks((int64_t)ntab) + 8), &bsum));
 
   const int g = grid_for(n);
   hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint32_t *)keys,
-                     (uint32_t *)vals, ctx->cell_start);
-  O3D_TRY(o3d_exclusive_scan_u32(ctx, ctx->cell_start, (uint32_t *)bsum, (int64_t)ntab));
+                     (uint32_t *)vals);
   O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
                              n, ceil_log2((uint64_t)gp.ncell + 1)));
+  hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
+                     (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
   ctx->n_tgt_grid = nfinite;
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
