@@ -134,7 +134,8 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restr
 // (one wavefront, 64 probes per step), counted in LDS, scanned in the workgroup and written out once, coalesced -- the
 // table is written exactly once and never read (the earlier version cleared it, built a histogram with one global atomic
 // per point on a table far larger than any cache, and ran a three-kernel scan over all of it).
-constexpr int kCtCells = 8192;
+constexpr int kCtCells = 8192;      // cells per workgroup: tables of millions of cells
+constexpr int kCtCellsSmall = 1024;  // small tables: more workgroups, a short count loop each
 __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ keys, uint32_t n, uint64_t target, int lane) {
   uint32_t lo = 0, hi = n;
   while (hi > lo) {
@@ -151,18 +152,19 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
   return lo;
 }
 
+template <int kCells>
 __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ cell_start,
                                                            uint64_t ntab) {
-  __shared__ __align__(16) uint32_t cnt[kCtCells];
+  __shared__ __align__(16) uint32_t cnt[kCells];
   __shared__ uint32_t bounds[2];
   __shared__ uint32_t wsum[O3D_BLOCK / O3D_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t c0 = (uint64_t)blockIdx.x * kCtCells;
+  const uint64_t c0 = (uint64_t)blockIdx.x * kCells;
   if (wave < 2) {  // the two ends of the key range, one wavefront each
-    const uint32_t a = wave_lower_bound(keys, n, c0 + (uint64_t)wave * kCtCells, lane);
+    const uint32_t a = wave_lower_bound(keys, n, c0 + (uint64_t)wave * kCells, lane);
     if (lane == 0) bounds[wave] = a;
   }
-  constexpr int kQuads = kCtCells / (4 * O3D_BLOCK);  // uint4 stores per thread
+  constexpr int kQuads = kCells / (4 * O3D_BLOCK);  // uint4 stores per thread
   uint4 *cnt4 = reinterpret_cast<uint4 *>(cnt);
 #pragma unroll
   for (int q = 0; q < kQuads; q++) cnt4[q * O3D_BLOCK + tid] = make_uint4(0, 0, 0, 0);
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
     for (uint32_t p = p0 + tid; p < p1; p += O3D_BLOCK) atomicAdd(&cnt[(uint32_t)((uint64_t)keys[p] - c0)], 1u);
     __syncthreads();
     // exclusive scan in place: each wavefront over its own quarter, 256 cells (one uint4 per lane) at a time
-    constexpr int kWaveCells = kCtCells / (O3D_BLOCK / O3D_WAVE);
+    constexpr int kWaveCells = kCells / (O3D_BLOCK / O3D_WAVE);
     uint32_t carry = 0;
 #pragma unroll 2
     for (int it = 0; it < kWaveCells / (4 * O3D_WAVE); it++) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
     const int qi = q * O3D_BLOCK + tid;
     uint4 v = make_uint4(p0, p0, p0, p0);
     if (p1 > p0) {
-      constexpr int kWaveQuads = kCtCells / (O3D_BLOCK / O3D_WAVE) / 4;
+      constexpr int kWaveQuads = kCells / (O3D_BLOCK / O3D_WAVE) / 4;
       uint32_t base = p0;
       for (int w = 0; w < qi / kWaveQuads; w++) base += wsum[w];
       const uint4 e = cnt4[qi];
@@ -417,8 +419,12 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
                      (uint32_t *)vals);
   O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
                              n, ceil_log2((uint64_t)gp.ncell + 1)));
-  hipLaunchKernelGGL(k_cell_table, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
-                     (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+  if (ntab > (4u << 20))
+    hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
+                       (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+  else
+    hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK), 0,
+                       ctx->stream, (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
   ctx->n_tgt_grid = nfinite;
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,

@@ -985,7 +985,6 @@ __device__ __forceinline__ void ldlt_swap(double (&M)[36]) {
   for (int i = P + 1; i < 6; i++) { t = MR(i, K); MR(i, K) = MR(i, P); MR(i, P) = t; }
 #pragma unroll
   for (int i = K + 1; i < P; i++) { t = MR(i, K); MR(i, K) = MR(P, i); MR(P, i) = t; }
-  t = MR(K, K); MR(K, K) = MR(P, P); MR(P, P) = t;
 }
 template <int K>
 __device__ __forceinline__ void ldlt_swap_dyn(double (&M)[36], int p) {
@@ -997,18 +996,25 @@ __device__ __forceinline__ void ldlt_swap_dyn(double (&M)[36], int p) {
     case 5: if constexpr (K < 5) ldlt_swap<K, 5>(M); break;
     default: break;
   }
+  // the diagonal pair by selects on the values: written as one more swap inside the cases, the compiler merges the cases
+  // into one swap at a dynamic address and the diagonal goes to scratch memory after all
+  const double dk = MR(K, K);
+  double dp = dk;
+#pragma unroll
+  for (int i = K + 1; i < 6; i++) dp = p == i ? MR(i, i) : dp;
+#pragma unroll
+  for (int i = K + 1; i < 6; i++) MR(i, i) = p == i ? dk : MR(i, i);
+  MR(K, K) = dp;
 }
 template <int K>
-__device__ __forceinline__ void vec_swap_dyn(double (&y)[6], int p) {
-  double t;
-  switch (p) {
-    case 1: if constexpr (K < 1) { t = y[K]; y[K] = y[1]; y[1] = t; } break;
-    case 2: if constexpr (K < 2) { t = y[K]; y[K] = y[2]; y[2] = t; } break;
-    case 3: if constexpr (K < 3) { t = y[K]; y[K] = y[3]; y[3] = t; } break;
-    case 4: if constexpr (K < 4) { t = y[K]; y[K] = y[4]; y[4] = t; } break;
-    case 5: if constexpr (K < 5) { t = y[K]; y[K] = y[5]; y[5] = t; } break;
-    default: break;
-  }
+__device__ __forceinline__ void vec_swap_dyn(double (&y)[6], int p) {  // by selects, for the same reason
+  const double yk = y[K];
+  double yp = yk;
+#pragma unroll
+  for (int i = K + 1; i < 6; i++) yp = p == i ? y[i] : yp;
+#pragma unroll
+  for (int i = K + 1; i < 6; i++) y[i] = p == i ? yk : y[i];
+  y[K] = yp;
 }
 template <int K>
 __device__ __forceinline__ void ldlt_step(double (&M)[36], int (&tr)[6]) {
@@ -1220,7 +1226,7 @@ __device__ __forceinline__ void write_log_row(const IcpState *st, const double *
   log[(size_t)pass * O3D_LOG_STRIDE + e] = v;
 }
 
-__device__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
+__device__ __forceinline__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
   if (nc > 0.0) {  // Registration.cpp:82-89

@@ -60,7 +60,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_hist(const KeyT *__restrict_
   hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-template <typename KeyT>
+// FUSED (few tiles): the table holds the raw per-tile counts and every workgroup derives its 256 digit bases from them
+// itself (a row sum and a partial row sum per digit, one workgroup scan) -- three scan launches fewer per pass, which is
+// most of the time of a pass over a small cloud.
+constexpr uint32_t kFusedTiles = 64;
+template <typename KeyT, bool FUSED>
 __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                              KeyT *__restrict__ out_keys, uint32_t *__restrict__ out_vals,
                                                              const uint32_t *__restrict__ hist_scanned, int64_t n, int shift,
@@ -70,7 +74,21 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) wcnt[w][threadIdx.x] = 0;
-  gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
+  if (FUSED) {
+    __shared__ uint32_t wt[kWaves];
+    const uint32_t *row = hist_scanned + (size_t)threadIdx.x * ntiles;
+    uint32_t total = 0, mine = 0;
+#pragma unroll 8
+    for (uint32_t t = 0; t < ntiles; t++) {
+      const uint32_t c = row[t];
+      total += c;
+      mine += t < blockIdx.x ? c : 0u;
+    }
+    uint32_t all;
+    gbase[threadIdx.x] = block_exclusive_scan(total, wt, &all) + mine;  // (ends with a workgroup barrier)
+  } else {
+    gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
+  }
   __syncthreads();
 
   const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * (O3D_WAVE * kSortItems);
@@ -206,9 +224,14 @@ int radix_sort_impl(o3d_ctx *ctx, KeyT *keys, uint32_t *vals, KeyT *tmp_keys, ui
   for (int p = 0; p < passes; p++) {
     const int shift = 8 * p;
     hipLaunchKernelGGL(k_sort_hist<KeyT>, dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, hist, n, shift, ntiles);
-    O3D_TRY(o3d_exclusive_scan_u32(ctx, hist, bsums, nh));
-    hipLaunchKernelGGL(k_sort_scatter<KeyT>, dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, va, kb, vb, hist, n, shift,
-                       ntiles);
+    if (ntiles <= kFusedTiles) {
+      hipLaunchKernelGGL((k_sort_scatter<KeyT, true>), dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, va, kb, vb, hist, n,
+                         shift, ntiles);
+    } else {
+      O3D_TRY(o3d_exclusive_scan_u32(ctx, hist, bsums, nh));
+      hipLaunchKernelGGL((k_sort_scatter<KeyT, false>), dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, va, kb, vb, hist, n,
+                         shift, ntiles);
+    }
     KeyT *tk = ka; ka = kb; kb = tk;
     uint32_t *tv = va; va = vb; vb = tv;
   }
