@@ -222,7 +222,7 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 }
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
-constexpr int kNrmLoads = 8;   // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
+constexpr int kNrmLoads = 12;  // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
 constexpr int kMaxKnn = 128;  // 16 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel.
@@ -346,55 +346,99 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
     l.count = 0;
     int count = 0;                                  // MODE 1
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // cumulants
-    for (int R = 1;; R++) {
-      // shell R of the cube around the query's cell (R == 1: the whole 3x3x3 block)
-      for (int dz = -R; dz <= R; dz++) {
-        const int zz = cz + dz;
-        if (zz < 0 || zz >= gp.nz) continue;
-        for (int dy = -R; dy <= R; dy++) {
-          const int yy = cy + dy;
-          if (yy < 0 || yy >= gp.ny) continue;
-          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-          const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
-          const int nseg = face ? 1 : 2;
-          for (int sgi = 0; sgi < nseg; sgi++) {
-            int xa, xb;  // unpadded cell range of this piece of the row
-            if (face) { xa = cx - R; xb = cx + R; }
-            else if (sgi == 0) { xa = xb = cx - R; }
-            else { xa = xb = cx + R; }
-            xa = max(xa, -1); xb = min(xb, gp.nx);
-            if (xa > xb) continue;
-            const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-            for (uint32_t j0 = s; j0 < e; j0 += kNrmLoads) {  // candidate loads in flight; processed in run order
-              double4 tq[kNrmLoads];
+    auto visit = [&](const double4 &t, uint32_t j, bool real) {
+      const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+      double d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (!real) d2 = INFINITY;  // a padding slot of the batch: rejected by every mode below
+      if (MODE == 1) {
+        if (d2 < thr) {
+          count++;
+          c[0] += t.x; c[1] += t.y; c[2] += t.z;
+          c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+          c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+        }
+      } else if (d2 <= klist_worst(l)) {
+        klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+      }
+    };
+    {
+      // Shell 1, the whole 3x3x3 block: nine rows (dz outer, dy inner), each ONE run of the cell-ordered cloud.  The nine
+      // pairs of bounds are loaded together and the runs are walked as one flattened sequence, kNrmLoads candidates in
+      // flight at a time across row ends -- at ~1 wavefront per SIMD every dependent round trip is exposed, and row by row
+      // there were two per row (bounds, candidates) plus one per further kNrmLoads candidates.  Visiting order unchanged.
+      uint32_t rs[9], re[9];
+      const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
 #pragma unroll
-              for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
+      for (int r = 0; r < 9; r++) {
+        const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
+        const bool ok = zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny;
+        const uint32_t row = ok ? ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp : 0u;
+        const uint32_t s0 = cell_start[row + (uint32_t)(xa + 1)], e0 = cell_start[row + (uint32_t)(xb + 2)];
+        rs[r] = ok ? s0 : 0u;
+        re[r] = ok ? e0 : 0u;
+      }
+      int r = 0;
+      uint32_t j = rs[0], e = re[0];
+      auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
+        while (j >= e && r < 8) {
+          r++;
 #pragma unroll
-              for (int u = 0; u < kNrmLoads; u++) {
-                const uint32_t j = j0 + (uint32_t)u;
-                const double4 t = tq[u];
-                const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
-                double d2 = ddx * ddx;
-                d2 = d2 + ddy * ddy;
-                d2 = d2 + ddz * ddz;
-                if (j >= e) d2 = INFINITY;  // past the end of the run: rejected by every mode below
-                if (MODE == 1) {
-                  if (d2 < thr) {
-                    count++;
-                    c[0] += t.x; c[1] += t.y; c[2] += t.z;
-                    c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
-                    c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
-                  }
-                } else if (d2 <= klist_worst(l)) {
-                  klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
-                }
+          for (int i = 1; i < 9; i++) {
+            j = r == i ? rs[i] : j;
+            e = r == i ? re[i] : e;
+          }
+        }
+      };
+      next_row();
+      while (j < e) {
+        uint32_t jj[kNrmLoads];
+        bool real[kNrmLoads];
+#pragma unroll
+        for (int u = 0; u < kNrmLoads; u++) {
+          real[u] = j < e;
+          jj[u] = real[u] ? j : (uint32_t)p;
+          if (real[u]) { j++; next_row(); }
+        }
+        double4 tq[kNrmLoads];
+#pragma unroll
+        for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[jj[u]];
+#pragma unroll
+        for (int u = 0; u < kNrmLoads; u++) visit(tq[u], jj[u], real[u]);
+      }
+    }
+    for (int R = 1; MODE == 0; R++) {  // KNN: further shells of the cube around the query's cell
+      if (R > 1) {
+        for (int dz = -R; dz <= R; dz++) {
+          const int zz = cz + dz;
+          if (zz < 0 || zz >= gp.nz) continue;
+          for (int dy = -R; dy <= R; dy++) {
+            const int yy = cy + dy;
+            if (yy < 0 || yy >= gp.ny) continue;
+            const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+            const bool face = dz == -R || dz == R || dy == -R || dy == R;
+            const int nseg = face ? 1 : 2;
+            for (int sgi = 0; sgi < nseg; sgi++) {
+              int xa, xb;  // unpadded cell range of this piece of the row
+              if (face) { xa = cx - R; xb = cx + R; }
+              else if (sgi == 0) { xa = xb = cx - R; }
+              else { xa = xb = cx + R; }
+              xa = max(xa, -1); xb = min(xb, gp.nx);
+              if (xa > xb) continue;
+              const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+              for (uint32_t j0 = s; j0 < e; j0 += kNrmLoads) {  // candidate loads in flight; processed in run order
+                double4 tq[kNrmLoads];
+#pragma unroll
+                for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
+#pragma unroll
+                for (int u = 0; u < kNrmLoads; u++) visit(tq[u], j0 + (uint32_t)u, j0 + (uint32_t)u < e);
               }
             }
           }
         }
       }
-      if (MODE != 0) break;  // h >= radius: the 3x3x3 block is complete
-      // KNN: every unsearched point is at least R*h away (minus rounding); done once the k-th distance is inside
+      // every unsearched point is at least R*h away (minus rounding); done once the k-th distance is inside
       if (R >= max_dim) break;
       if (l.count == l.cap) {
         const double reach = (double)R * gp.h * (1.0 - 1e-6);
@@ -405,11 +449,19 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
     if (MODE != 1) {
       klist_sort(l);
       k = l.count;
-      for (int i = 0; i < k; i++) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
-        const double4 t = pts[l.pos[i * kNrmBlock]];
-        c[0] += t.x; c[1] += t.y; c[2] += t.z;
-        c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
-        c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+      for (int i0 = 0; i0 < k; i0 += kNrmLoads) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
+        double4 tq[kNrmLoads];
+#pragma unroll
+        for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[l.pos[min(i0 + u, k - 1) * kNrmBlock]];
+#pragma unroll
+        for (int u = 0; u < kNrmLoads; u++) {
+          if (i0 + u < k) {
+            const double4 t = tq[u];
+            c[0] += t.x; c[1] += t.y; c[2] += t.z;
+            c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+            c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
+          }
+        }
       }
     }
     double nv[3] = {0.0, 0.0, 1.0};
