@@ -223,7 +223,7 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
 constexpr int kNrmLoads = 12;  // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
-constexpr int kMaxKnn = 128;  // 16 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
+constexpr int kMaxKnn = 128;  // 12 B per list entry and lane: 96 KiB of the CU's 160 KiB LDS for one wavefront
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel.
 template <typename K>
@@ -236,67 +236,78 @@ int allow_lds(o3d_ctx *ctx, K kernel, size_t lds) {
 // k-best list of one lane.  While candidates arrive it is a binary MAX-heap on (d2, index) -- the worst kept entry is the
 // root, an insertion moves at most log2(k) entries (a sorted list moves k/2 on average and, lanes inserting at different
 // places, nearly k per wavefront step) -- and klist_sort turns it in place into the ascending order FLANN returns and
-// ComputeNormal sums in.
+// ComputeNormal sums in.  An entry is 12 bytes of LDS, distance and position: the original index, which only breaks ties
+// between equal distances, is read back from the cloud (pts[pos].w) when two distances ARE equal.  The lists are what
+// limits the wavefronts per CU, and a third array for the index cost a quarter of them.
 struct KList {
   double *d2;     // LDS, stride kNrmBlock
-  uint32_t *pos;  // LDS, stride kNrmBlock: position in tgt_sorted
-  uint32_t *idx;  // LDS, stride kNrmBlock: original index (tie-break)
+  uint32_t *pos;  // LDS, stride kNrmBlock: position in the cell-ordered cloud
+  const double4 *pts;  // the cell-ordered cloud (w = original index)
   int cap, count;
   double thr;     // strict bound on d2 (INFINITY for pure KNN)
 };
+constexpr size_t kListEntryBytes = sizeof(double) + sizeof(uint32_t);
 
-__device__ __forceinline__ bool kl_less(double d1, uint32_t i1, double d2, uint32_t i2) {
-  return d1 < d2 || (d1 == d2 && i1 < i2);
+__device__ __forceinline__ void klist_bind(KList &l, unsigned char *smem, int lane, int knn, const double4 *pts) {
+  l.d2 = reinterpret_cast<double *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.pts = pts;
+  l.cap = knn;
+}
+
+__device__ __forceinline__ uint32_t kl_index(const KList &l, uint32_t pos) {
+  return (uint32_t)__double_as_longlong(l.pts[pos].w);
+}
+// (d1, index of p1) < (d2, index of p2); the indices are looked up for equal distances only
+__device__ __forceinline__ bool kl_less(const KList &l, double d1, uint32_t p1, double d2, uint32_t p2) {
+  if (d1 != d2) return d1 < d2;
+  return kl_index(l, p1) < kl_index(l, p2);
 }
 
 __device__ __forceinline__ double klist_worst(const KList &l) {
   return (l.count == l.cap) ? l.d2[0] : l.thr;
 }
 
-// Put (d, id, pos) into the hole at the root of the heap of `n` entries and let it sink.
-__device__ __forceinline__ void klist_sink(KList &l, int n, double d, uint32_t id, uint32_t pos) {
+// Put (d, pos) into the hole at the root of the heap of `n` entries and let it sink.
+__device__ __forceinline__ void klist_sink(KList &l, int n, double d, uint32_t pos) {
   int i = 0;
   for (;;) {
     int c = 2 * i + 1;
     if (c >= n) break;
     double cd = l.d2[c * kNrmBlock];
-    uint32_t ci = l.idx[c * kNrmBlock];
+    uint32_t cp = l.pos[c * kNrmBlock];
     if (c + 1 < n) {
       const double rd = l.d2[(c + 1) * kNrmBlock];
-      const uint32_t ri = l.idx[(c + 1) * kNrmBlock];
-      if (kl_less(cd, ci, rd, ri)) { c++; cd = rd; ci = ri; }
+      const uint32_t rp = l.pos[(c + 1) * kNrmBlock];
+      if (kl_less(l, cd, cp, rd, rp)) { c++; cd = rd; cp = rp; }
     }
-    if (!kl_less(d, id, cd, ci)) break;
+    if (!kl_less(l, d, pos, cd, cp)) break;
     l.d2[i * kNrmBlock] = cd;
-    l.idx[i * kNrmBlock] = ci;
-    l.pos[i * kNrmBlock] = l.pos[c * kNrmBlock];
+    l.pos[i * kNrmBlock] = cp;
     i = c;
   }
   l.d2[i * kNrmBlock] = d;
-  l.idx[i * kNrmBlock] = id;
   l.pos[i * kNrmBlock] = pos;
 }
 
-__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t id, uint32_t pos) {
+__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t pos) {
   if (!(d < l.thr)) return;
   if (l.count == l.cap) {  // replace the worst entry if the candidate is better
-    if (!kl_less(d, id, l.d2[0], l.idx[0])) return;
-    klist_sink(l, l.cap, d, id, pos);
+    if (!kl_less(l, d, pos, l.d2[0], l.pos[0])) return;
+    klist_sink(l, l.cap, d, pos);
     return;
   }
   int i = l.count++;
   while (i > 0) {  // rise
     const int p = (i - 1) >> 1;
     const double pd = l.d2[p * kNrmBlock];
-    const uint32_t pi = l.idx[p * kNrmBlock];
-    if (!kl_less(pd, pi, d, id)) break;
+    const uint32_t pp = l.pos[p * kNrmBlock];
+    if (!kl_less(l, pd, pp, d, pos)) break;
     l.d2[i * kNrmBlock] = pd;
-    l.idx[i * kNrmBlock] = pi;
-    l.pos[i * kNrmBlock] = l.pos[p * kNrmBlock];
+    l.pos[i * kNrmBlock] = pp;
     i = p;
   }
   l.d2[i * kNrmBlock] = d;
-  l.idx[i * kNrmBlock] = id;
   l.pos[i * kNrmBlock] = pos;
 }
 
@@ -304,11 +315,10 @@ __device__ __forceinline__ void klist_add(KList &l, double d, uint32_t id, uint3
 __device__ __forceinline__ void klist_sort(KList &l) {
   for (int end = l.count - 1; end > 0; end--) {
     const double d = l.d2[end * kNrmBlock];
-    const uint32_t id = l.idx[end * kNrmBlock], pos = l.pos[end * kNrmBlock];
+    const uint32_t pos = l.pos[end * kNrmBlock];
     l.d2[end * kNrmBlock] = l.d2[0];
-    l.idx[end * kNrmBlock] = l.idx[0];
     l.pos[end * kNrmBlock] = l.pos[0];
-    klist_sink(l, end, d, id, pos);
+    klist_sink(l, end, d, pos);
   }
 }
 
@@ -329,10 +339,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
-  l.d2 = reinterpret_cast<double *>(smem) + lane;
-  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
-  l.idx = l.pos + kNrmBlock * (size_t)knn;
-  l.cap = knn;
+  klist_bind(l, smem, lane, knn, pts);
   l.thr = (MODE == 0) ? INFINITY : thr;
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
 
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
           c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
         }
       } else if (d2 <= klist_worst(l)) {
-        klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+        klist_add(l, d2, j);
       }
     };
     {
@@ -560,10 +567,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
-  l.d2 = reinterpret_cast<double *>(smem) + lane;
-  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
-  l.idx = l.pos + kNrmBlock * (size_t)knn;
-  l.cap = knn;
+  klist_bind(l, smem, lane, knn, pts);
   l.thr = thr;
   for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
     const double4 q = pts[p];
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
           double d2 = ddx * ddx;
           d2 = d2 + ddy * ddy;
           d2 = d2 + ddz * ddz;
-          if (d2 <= klist_worst(l)) klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+          if (d2 <= klist_worst(l)) klist_add(l, d2, j);
         }
       }
     }
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
         double a[3], b;
         if (i < nn) {
           const double4 t = pts[l.pos[i * kNrmBlock]];
-          const size_t ai = l.idx[i * kNrmBlock];
+          const size_t ai = (size_t)__double_as_longlong(t.w);
           const double dot = ((t.x - q.x) * n0 + (t.y - q.y) * n1) + (t.z - q.z) * n2;
           a[0] = (t.x - dot * n0) - q.x; a[1] = (t.y - dot * n1) - q.y; a[2] = (t.z - dot * n2) - q.z;
           b = (colors[3 * ai] + colors[3 * ai + 1] + colors[3 * ai + 2]) / 3.0 - it;
@@ -634,10 +638,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
-  l.d2 = reinterpret_cast<double *>(smem) + lane;
-  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
-  l.idx = l.pos + kNrmBlock * (size_t)knn;
-  l.cap = knn;
+  klist_bind(l, smem, lane, knn, pts);
   l.thr = INFINITY;
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
   for (int64_t i = (int64_t)blockIdx.x * kNrmBlock + lane; i < n_q; i += (int64_t)gridDim.x * kNrmBlock) {
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
               if (MODE == 2) {
                 if (d2 < thr) count++;
               } else if (d2 <= klist_worst(l)) {
-                klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+                klist_add(l, d2, j);
               }
             }
           }
@@ -742,7 +743,7 @@ __device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__res
             double d2 = ddx * ddx;
             d2 = d2 + ddy * ddy;
             d2 = d2 + ddz * ddz;
-            if (d2 <= klist_worst(l)) klist_add(l, d2, (uint32_t)__double_as_longlong(t.w), j);
+            if (d2 <= klist_worst(l)) klist_add(l, d2, j);
           }
         }
       }
@@ -801,10 +802,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
-  l.d2 = reinterpret_cast<double *>(smem) + lane;
-  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
-  l.idx = l.pos + kNrmBlock * (size_t)knn;
-  l.cap = knn;
+  klist_bind(l, smem, lane, knn, pts);
   l.thr = knn_mode ? INFINITY : thr;
   for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
     const double4 q = pts[p];
@@ -819,7 +817,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
         const double n1[3] = {normals[3 * qi], normals[3 * qi + 1], normals[3 * qi + 2]};
         for (int k = 1; k < l.count; k++) {
           const double4 t = pts[l.pos[k * kNrmBlock]];
-          const size_t ti = l.idx[k * kNrmBlock];
+          const size_t ti = (size_t)__double_as_longlong(t.w);
           const double p2[3] = {t.x, t.y, t.z};
           const double n2[3] = {normals[3 * ti], normals[3 * ti + 1], normals[3 * ti + 2]};
           double f[4];
@@ -834,7 +832,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
       for (int k = 1; k < l.count; k++) {
         const double dist = l.d2[k * kNrmBlock];
         if (dist == 0.0) continue;
-        const double *sp = spfh + 33 * (size_t)l.idx[k * kNrmBlock];
+        const double *sp = spfh + 33 * (size_t)kl_index(l, l.pos[k * kNrmBlock]);
         for (int j = 0; j < 33; j++) {
           const double val = sp[j] / dist;
           sum[j / 11] += val;
@@ -971,7 +969,7 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     }
     const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126,148
     const int kk = degenerate ? 1 : (search_type == O3D_SEARCH_RADIUS ? 1 : knn);
-    const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)kk;
+    const size_t lds = kListEntryBytes * kNrmBlock * (size_t)kk;
     int64_t g = (p_hi - p_lo + kNrmBlock - 1) / kNrmBlock;
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
     const int by_pos = sharded ? 1 : 0;
@@ -1186,7 +1184,7 @@ int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_n
   const int64_t ng = ctx->n_tgt_grid;
   if (ng <= 0) return O3D_OK;
   const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:148
-  const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)max_nn;
+  const size_t lds = kListEntryBytes * kNrmBlock * (size_t)max_nn;
   int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
   g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
   O3D_TRY(allow_lds(ctx, k_color_gradient, lds));
@@ -1240,7 +1238,7 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
     else if (n_cloud > 0) O3D_TRY(build_knn_grid(ctx, d_cloud, n_cloud, &h));
     else O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, 0, 1.0));
     const int kk = (mode == 2) ? 1 : knn;
-    const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)kk;
+    const size_t lds = kListEntryBytes * kNrmBlock * (size_t)kk;
     int64_t g = (n_q + kNrmBlock - 1) / kNrmBlock;
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
     const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126
@@ -1311,7 +1309,7 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
     const int64_t ng = ctx->n_tgt_grid;
     if (ng > 0) {
       const double thr = (double)(float)(radius * radius);
-      const size_t lds = (sizeof(double) + 2 * sizeof(uint32_t)) * kNrmBlock * (size_t)knn;
+      const size_t lds = kListEntryBytes * kNrmBlock * (size_t)knn;
       int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
       g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
       O3D_TRY(allow_lds(ctx, k_fpfh<0>, lds));
