@@ -322,6 +322,88 @@ __device__ __forceinline__ void klist_sort(KList &l) {
   }
 }
 
+// Shell 1 of the cube around cell (cx, cy, cz), the whole 3x3x3 block: nine rows (dz outer, dy inner), each ONE run of the
+// cell-ordered cloud.  The nine pairs of bounds are loaded together and the runs are walked as one flattened sequence,
+// kNrmLoads candidates in flight at a time across row ends -- at ~1 wavefront per SIMD every dependent round trip is
+// exposed, and row by row there were two per row (bounds, candidates) plus one per further kNrmLoads candidates.
+// visit(point, position, real): real = 0 marks a padding slot of the last batch (`pad` is any valid position).
+template <typename F>
+__device__ __forceinline__ void walk_block3(const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                            const GridParams &gp, int cx, int cy, int cz, uint32_t pad, F &&visit) {
+  uint32_t rs[9], re[9];
+  const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
+    const bool ok = zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny;
+    const uint32_t row = ok ? ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp : 0u;
+    const uint32_t s0 = cell_start[row + (uint32_t)(xa + 1)], e0 = cell_start[row + (uint32_t)(xb + 2)];
+    rs[r] = ok ? s0 : 0u;
+    re[r] = ok ? e0 : 0u;
+  }
+  int r = 0;
+  uint32_t j = rs[0], e = re[0];
+  auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
+    while (j >= e && r < 8) {
+      r++;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        j = r == i ? rs[i] : j;
+        e = r == i ? re[i] : e;
+      }
+    }
+  };
+  next_row();
+  while (j < e) {
+    uint32_t jj[kNrmLoads];
+    bool real[kNrmLoads];
+#pragma unroll
+    for (int u = 0; u < kNrmLoads; u++) {
+      real[u] = j < e;
+      jj[u] = real[u] ? j : pad;
+      if (real[u]) { j++; next_row(); }
+    }
+    double4 tq[kNrmLoads];
+#pragma unroll
+    for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[jj[u]];
+#pragma unroll
+    for (int u = 0; u < kNrmLoads; u++) visit(tq[u], jj[u], real[u]);
+  }
+}
+
+// Shell R >= 2 of that cube (the cells at Chebyshev distance exactly R), row by row.
+template <typename F>
+__device__ __forceinline__ void walk_shell(const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                           const GridParams &gp, int cx, int cy, int cz, int R, F &&visit) {
+  for (int dz = -R; dz <= R; dz++) {
+    const int zz = cz + dz;
+    if (zz < 0 || zz >= gp.nz) continue;
+    for (int dy = -R; dy <= R; dy++) {
+      const int yy = cy + dy;
+      if (yy < 0 || yy >= gp.ny) continue;
+      const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
+      const bool face = dz == -R || dz == R || dy == -R || dy == R;
+      const int nseg = face ? 1 : 2;
+      for (int sgi = 0; sgi < nseg; sgi++) {
+        int xa, xb;  // unpadded cell range of this piece of the row
+        if (face) { xa = cx - R; xb = cx + R; }
+        else if (sgi == 0) { xa = xb = cx - R; }
+        else { xa = xb = cx + R; }
+        xa = max(xa, -1); xb = min(xb, gp.nx);
+        if (xa > xb) continue;
+        const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
+        for (uint32_t j0 = s; j0 < e; j0 += kNrmLoads) {  // candidate loads in flight; processed in run order
+          double4 tq[kNrmLoads];
+#pragma unroll
+          for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
+#pragma unroll
+          for (int u = 0; u < kNrmLoads; u++) visit(tq[u], j0 + (uint32_t)u, j0 + (uint32_t)u < e);
+        }
+      }
+    }
+  }
+}
+
 // Per point: neighbours by KNN / radius / hybrid search over the cloud's own cell grid, cumulants in neighbour order,
 // covariance, FastEigen3x3, fallbacks and orientation against an existing normal (EstimateNormals.cpp:330-350).
 //   MODE 0 KNN: shells of cells are added until the k-th distance is inside the searched cube.
@@ -370,81 +452,9 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
         klist_add(l, d2, j);
       }
     };
-    {
-      // Shell 1, the whole 3x3x3 block: nine rows (dz outer, dy inner), each ONE run of the cell-ordered cloud.  The nine
-      // pairs of bounds are loaded together and the runs are walked as one flattened sequence, kNrmLoads candidates in
-      // flight at a time across row ends -- at ~1 wavefront per SIMD every dependent round trip is exposed, and row by row
-      // there were two per row (bounds, candidates) plus one per further kNrmLoads candidates.  Visiting order unchanged.
-      uint32_t rs[9], re[9];
-      const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
-        const bool ok = zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny;
-        const uint32_t row = ok ? ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp : 0u;
-        const uint32_t s0 = cell_start[row + (uint32_t)(xa + 1)], e0 = cell_start[row + (uint32_t)(xb + 2)];
-        rs[r] = ok ? s0 : 0u;
-        re[r] = ok ? e0 : 0u;
-      }
-      int r = 0;
-      uint32_t j = rs[0], e = re[0];
-      auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
-        while (j >= e && r < 8) {
-          r++;
-#pragma unroll
-          for (int i = 1; i < 9; i++) {
-            j = r == i ? rs[i] : j;
-            e = r == i ? re[i] : e;
-          }
-        }
-      };
-      next_row();
-      while (j < e) {
-        uint32_t jj[kNrmLoads];
-        bool real[kNrmLoads];
-#pragma unroll
-        for (int u = 0; u < kNrmLoads; u++) {
-          real[u] = j < e;
-          jj[u] = real[u] ? j : (uint32_t)p;
-          if (real[u]) { j++; next_row(); }
-        }
-        double4 tq[kNrmLoads];
-#pragma unroll
-        for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[jj[u]];
-#pragma unroll
-        for (int u = 0; u < kNrmLoads; u++) visit(tq[u], jj[u], real[u]);
-      }
-    }
+    walk_block3(pts, cell_start, gp, cx, cy, cz, (uint32_t)p, visit);
     for (int R = 1; MODE == 0; R++) {  // KNN: further shells of the cube around the query's cell
-      if (R > 1) {
-        for (int dz = -R; dz <= R; dz++) {
-          const int zz = cz + dz;
-          if (zz < 0 || zz >= gp.nz) continue;
-          for (int dy = -R; dy <= R; dy++) {
-            const int yy = cy + dy;
-            if (yy < 0 || yy >= gp.ny) continue;
-            const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-            const bool face = dz == -R || dz == R || dy == -R || dy == R;
-            const int nseg = face ? 1 : 2;
-            for (int sgi = 0; sgi < nseg; sgi++) {
-              int xa, xb;  // unpadded cell range of this piece of the row
-              if (face) { xa = cx - R; xb = cx + R; }
-              else if (sgi == 0) { xa = xb = cx - R; }
-              else { xa = xb = cx + R; }
-              xa = max(xa, -1); xb = min(xb, gp.nx);
-              if (xa > xb) continue;
-              const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-              for (uint32_t j0 = s; j0 < e; j0 += kNrmLoads) {  // candidate loads in flight; processed in run order
-                double4 tq[kNrmLoads];
-#pragma unroll
-                for (int u = 0; u < kNrmLoads; u++) tq[u] = pts[min(j0 + (uint32_t)u, e - 1)];
-#pragma unroll
-                for (int u = 0; u < kNrmLoads; u++) visit(tq[u], j0 + (uint32_t)u, j0 + (uint32_t)u < e);
-              }
-            }
-          }
-        }
-      }
+      if (R > 1) walk_shell(pts, cell_start, gp, cx, cy, cz, R, visit);
       // every unsearched point is at least R*h away (minus rounding); done once the k-th distance is inside
       if (R >= max_dim) break;
       if (l.count == l.cap) {
@@ -576,25 +586,13 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
     const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
     l.count = 0;
-    for (int dz = -1; dz <= 1; dz++) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= gp.nz) continue;
-      for (int dy = -1; dy <= 1; dy++) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= gp.ny) continue;
-        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-        const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
-        const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-        for (uint32_t j = s; j < e; j++) {
-          const double4 t = pts[j];
-          const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
-          double d2 = ddx * ddx;
-          d2 = d2 + ddy * ddy;
-          d2 = d2 + ddz * ddz;
-          if (d2 <= klist_worst(l)) klist_add(l, d2, j);
-        }
-      }
-    }
+    walk_block3(pts, cell_start, gp, cx, cy, cz, (uint32_t)p, [&](const double4 &t, uint32_t j, bool real) {
+      const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+      double d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (real && d2 <= klist_worst(l)) klist_add(l, d2, j);
+    });
     double g[3] = {0.0, 0.0, 0.0};
     klist_sort(l);
     const int nn = l.count;
@@ -650,39 +648,21 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
     const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
     l.count = 0;
     int count = 0;
-    for (int R = 1;; R++) {
-      for (int dz = -R; dz <= R; dz++) {
-        const int zz = cz + dz;
-        if (zz < 0 || zz >= gp.nz) continue;
-        for (int dy = -R; dy <= R; dy++) {
-          const int yy = cy + dy;
-          if (yy < 0 || yy >= gp.ny) continue;
-          const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-          const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
-          const int nseg = face ? 1 : 2;
-          for (int sgi = 0; sgi < nseg; sgi++) {
-            int xa, xb;
-            if (face) { xa = cx - R; xb = cx + R; }
-            else if (sgi == 0) { xa = xb = cx - R; }
-            else { xa = xb = cx + R; }
-            xa = max(xa, -1); xb = min(xb, gp.nx);
-            if (xa > xb) continue;
-            const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-            for (uint32_t j = s; j < e; j++) {
-              const double4 t = pts[j];
-              const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
-              double d2 = ddx * ddx;
-              d2 = d2 + ddy * ddy;
-              d2 = d2 + ddz * ddz;
-              if (MODE == 2) {
-                if (d2 < thr) count++;
-              } else if (d2 <= klist_worst(l)) {
-                klist_add(l, d2, j);
-              }
-            }
-          }
-        }
+    auto visit = [&](const double4 &t, uint32_t j, bool real) {
+      const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
+      double d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (!real) return;
+      if (MODE == 2) {
+        if (d2 < thr) count++;
+      } else if (d2 <= klist_worst(l)) {
+        klist_add(l, d2, j);
       }
+    };
+    for (int R = 1;; R++) {
+      if (R == 1) walk_block3(pts, cell_start, gp, cx, cy, cz, 0u, visit);
+      else walk_shell(pts, cell_start, gp, cx, cy, cz, R, visit);
       if (MODE == 2) break;  // h >= radius: the 3x3x3 block is complete
       if (R >= max_dim) break;
       if (l.count == l.cap) {
@@ -719,35 +699,16 @@ __device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__res
   const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
   l.count = 0;
+  auto visit = [&](const double4 &t, uint32_t j, bool real) {
+    const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
+    double d2 = ddx * ddx;
+    d2 = d2 + ddy * ddy;
+    d2 = d2 + ddz * ddz;
+    if (real && d2 <= klist_worst(l)) klist_add(l, d2, j);
+  };
   for (int R = 1;; R++) {
-    for (int dz = -R; dz <= R; dz++) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= gp.nz) continue;
-      for (int dy = -R; dy <= R; dy++) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= gp.ny) continue;
-        const uint32_t row = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp;
-        const bool face = (R == 1) || dz == -R || dz == R || dy == -R || dy == R;
-        const int nseg = face ? 1 : 2;
-        for (int sgi = 0; sgi < nseg; sgi++) {
-          int xa, xb;
-          if (face) { xa = cx - R; xb = cx + R; }
-          else if (sgi == 0) { xa = xb = cx - R; }
-          else { xa = xb = cx + R; }
-          xa = max(xa, -1); xb = min(xb, gp.nx);
-          if (xa > xb) continue;
-          const uint32_t s = cell_start[row + (uint32_t)(xa + 1)], e = cell_start[row + (uint32_t)(xb + 2)];
-          for (uint32_t j = s; j < e; j++) {
-            const double4 t = pts[j];
-            const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
-            double d2 = ddx * ddx;
-            d2 = d2 + ddy * ddy;
-            d2 = d2 + ddz * ddz;
-            if (d2 <= klist_worst(l)) klist_add(l, d2, j);
-          }
-        }
-      }
-    }
+    if (R == 1) walk_block3(pts, cell_start, gp, cx, cy, cz, 0u, visit);
+    else walk_shell(pts, cell_start, gp, cx, cy, cz, R, visit);
     if (!knn_mode) break;
     if (R >= max_dim) break;
     if (l.count == l.cap) {
