@@ -30,6 +30,18 @@ def test_volume_cloud_random_radius(ctx, oracle, offset, seed):
         _check(ctx, oracle, src, tgt, r)
 
 
+@pytest.mark.parametrize("n_tgt", [262144, 262145, 4096, 4097])
+def test_sort_variant_boundaries(ctx, oracle, n_tgt):
+    """Target sizes either side of a sort tile (4096 keys) and of the 64-tile limit below which a radix pass derives its
+    digit bases inside the scatter kernel; volume and sheet clouds (small and multi-million-cell prefix tables)."""
+    rng = np.random.default_rng(n_tgt)
+    tgt = rng.random((n_tgt, 3)) * np.array([4.0, 2.0, 1.0])
+    src = tgt[rng.integers(0, n_tgt, 20000)] + rng.normal(0, 0.004, (20000, 3))
+    _check(ctx, oracle, src, tgt, 0.02)                      # ~ 1.3 M cells at 262144 points
+    sheet = tgt * np.array([1.0, 1.0, 0.01])
+    _check(ctx, oracle, src * np.array([1.0, 1.0, 0.01]), sheet, 0.003)  # 1333 x 667 x few cells: > 4 M table entries
+
+
 def test_queries_on_cell_faces(ctx, oracle):
     """Targets on a lattice whose pitch equals the cell size; queries exactly on and a hair either side of faces."""
     rng = np.random.default_rng(5)
