@@ -311,6 +311,12 @@ O3D_API int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *s
                                                    double *out_T, int32_t *out_inlier, int64_t *out_n_inlier,
                                                    double *out_fitness, double *out_rmse);
 
+/* The correspondence_set_ of a RegistrationResult from the dense form the entry points above return (corr[i] = target index
+ * of source point i, or -1): {i, corr[i]} for every matched i in ascending i, the order Registration.cpp:60-75 builds it
+ * in (per-thread vectors of ascending i, concatenated in thread order under a static schedule).  Host memory only, no
+ * context.  out_pairs holds 2 * n int32 at most; returns the number of pairs. */
+O3D_API int64_t o3d_expand_correspondences(const int32_t *corr, int64_t n, int32_t *out_pairs);
+
 /* Tuning aid, no counterpart in the reference: best-of-reps milliseconds of one copy of `bytes` of pageable host memory to
  * (to_device = 1) or from the device, through the library's staged path (staged = 1) or plain hipMemcpyAsync. */
 O3D_API int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, int reps, double *out_ms);

@@ -92,6 +92,7 @@ _SIGNATURES = {
                                              C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "o3d_estimate_normals_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "o3d_debug_copy_check": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int64)]),
+    "o3d_expand_correspondences": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p]),
     "o3d_debug_copy_bench": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, c_dp]),
     "o3d_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),

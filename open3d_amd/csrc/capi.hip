@@ -72,6 +72,67 @@ int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes) {
   return O3D_OK;
 }
 
+static constexpr size_t kTmpIdleMax = (size_t)16 << 30;
+
+hipError_t o3d_tmp_alloc(o3d_ctx *ctx, void **out, size_t bytes) {
+  const size_t want = bytes < 256 ? 256 : bytes;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->tmp_idle.size(); i++) {
+    const size_t cap = ctx->tmp_idle[i].cap;
+    if (cap >= want && cap <= 2 * want + ((size_t)1 << 20) && (best < 0 || cap < ctx->tmp_idle[best].cap)) best = i;
+  }
+  if (best >= 0) {
+    const o3d_ctx::TmpBlock b = ctx->tmp_idle[best];
+    ctx->tmp_idle.erase(ctx->tmp_idle.begin() + best);
+    ctx->tmp_idle_bytes -= b.cap;
+    ctx->tmp_live.push_back(b);
+    *out = b.p;
+    return hipSuccess;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory && !ctx->tmp_idle.empty()) {  // give the cache back and try once more
+    (void)hipGetLastError();
+    for (const o3d_ctx::TmpBlock &b : ctx->tmp_idle) (void)hipFree(b.p);
+    ctx->tmp_idle.clear();
+    ctx->tmp_idle_bytes = 0;
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) return e;
+  ctx->tmp_live.push_back({p, want});
+  *out = p;
+  return hipSuccess;
+}
+
+void o3d_tmp_free(o3d_ctx *ctx, void *p) {
+  if (!p) return;
+  for (size_t i = 0; i < ctx->tmp_live.size(); i++) {
+    if (ctx->tmp_live[i].p != p) continue;
+    const o3d_ctx::TmpBlock b = ctx->tmp_live[i];
+    ctx->tmp_live.erase(ctx->tmp_live.begin() + (long)i);
+    // the block may go to another call's copy streams next: nothing of this call may still be using it
+    (void)hipStreamSynchronize(ctx->stream);
+    if (b.cap > kTmpIdleMax / 2 || ctx->tmp_idle.size() >= 32) { (void)hipFree(b.p); return; }
+    ctx->tmp_idle.push_back(b);
+    ctx->tmp_idle_bytes += b.cap;
+    while (ctx->tmp_idle_bytes > kTmpIdleMax) {  // oldest first
+      ctx->tmp_idle_bytes -= ctx->tmp_idle.front().cap;
+      (void)hipFree(ctx->tmp_idle.front().p);
+      ctx->tmp_idle.erase(ctx->tmp_idle.begin());
+    }
+    return;
+  }
+  (void)hipFree(p);  // not one of ours
+}
+
+void o3d_tmp_release_all(o3d_ctx *ctx) {
+  for (const o3d_ctx::TmpBlock &b : ctx->tmp_idle) (void)hipFree(b.p);
+  for (const o3d_ctx::TmpBlock &b : ctx->tmp_live) (void)hipFree(b.p);
+  ctx->tmp_idle.clear();
+  ctx->tmp_live.clear();
+  ctx->tmp_idle_bytes = 0;
+}
+
 int o3d_scratch(o3d_ctx *ctx, int slot, size_t bytes, void **out) {
   O3D_TRY(o3d_reserve(ctx, &ctx->scratch[slot], &ctx->scratch_cap[slot], bytes));
   *out = ctx->scratch[slot];
@@ -166,15 +227,17 @@ static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full 
 namespace {
 struct DevBufs {
   std::vector<void *> owned;
+  o3d_ctx *owner = nullptr;
   ~DevBufs() {
-    for (void *p : owned) (void)hipFree(p);
+    for (void *p : owned) o3d_tmp_free(owner, p);
   }
   template <typename T>
   int in(o3d_ctx *ctx, const T *p, size_t count, int mem, const T **out) {
     *out = p;
     if (!p || mem != O3D_MEM_HOST) return O3D_OK;
     void *d = nullptr;
-    O3D_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+    owner = ctx;
+    O3D_HIP(ctx, o3d_tmp_alloc(ctx, &d, sizeof(T) * (count ? count : 1)));
     owned.push_back(d);
     if (count) O3D_HIP(ctx, o3d_h2d(ctx, d, p, sizeof(T) * count));
     *out = (const T *)d;
@@ -183,7 +246,8 @@ struct DevBufs {
   template <typename T>
   int tmp(o3d_ctx *ctx, size_t count, T **out) {
     void *d = nullptr;
-    O3D_HIP(ctx, hipMalloc(&d, sizeof(T) * (count ? count : 1)));
+    owner = ctx;
+    O3D_HIP(ctx, o3d_tmp_alloc(ctx, &d, sizeof(T) * (count ? count : 1)));
     owned.push_back(d);
     *out = (T *)d;
     return O3D_OK;
@@ -242,6 +306,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->sint_sorted) (void)hipFree(ctx->sint_sorted);
   for (hipEvent_t e : ctx->prof_ev)
     if (e) (void)hipEventDestroy(e);
+  o3d_tmp_release_all(ctx);
   o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1359,6 +1424,19 @@ int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, 
 
 // Self-check of the staged copy path (xfer.hip): two pattern-filled pageable buffers go up back to back and come down
 // back to back, `rounds` times; *out_mismatches = number of 8-byte words that came back different.
+int64_t o3d_expand_correspondences(const int32_t *corr, int64_t n, int32_t *out_pairs) {
+  if (!corr || !out_pairs || n <= 0) return 0;
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (corr[i] >= 0) {
+      out_pairs[2 * m] = (int32_t)i;
+      out_pairs[2 * m + 1] = corr[i];
+      m++;
+    }
+  }
+  return m;
+}
+
 int o3d_debug_copy_check(o3d_ctx *ctx, size_t bytes, int rounds, int64_t *out_mismatches) {
   if (!ctx || !out_mismatches || bytes < 16) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);

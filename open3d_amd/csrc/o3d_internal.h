@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/o3d_icp.h"
 
@@ -114,6 +115,10 @@ struct o3d_ctx {
   size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void *pinned = nullptr;  // 4 KiB pinned host staging
   void *xfer = nullptr;    // staged-copy state (xfer.hip), created by the first large host <-> device copy
+  // per-call device temporaries (copies of host inputs, staged outputs): blocks are kept between calls, see o3d_tmp_alloc
+  struct TmpBlock { void *p; size_t cap; };
+  std::vector<TmpBlock> tmp_idle, tmp_live;
+  size_t tmp_idle_bytes = 0;
 };
 
 // ---- helpers ----------------------------------------------------------------
@@ -133,6 +138,12 @@ int o3d_fail(o3d_ctx *ctx, int status, const char *fmt, ...);
 
 // grow-only device buffer
 int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes);
+// Device memory for the duration of one call.  hipMalloc + hipFree of a few hundred MB cost milliseconds per call (the free
+// synchronises the device); a call that is repeated gets the blocks of the previous one back instead.  Blocks up to twice
+// the requested size are reused; at most kTmpIdleMax bytes stay cached; o3d_tmp_release_all gives everything back.
+hipError_t o3d_tmp_alloc(o3d_ctx *ctx, void **out, size_t bytes);
+void o3d_tmp_free(o3d_ctx *ctx, void *p);
+void o3d_tmp_release_all(o3d_ctx *ctx);
 int o3d_scratch(o3d_ctx *ctx, int slot, size_t bytes, void **out);
 
 // ---- xfer.hip: copies of caller (pageable) buffers, ordered with ctx->stream -------

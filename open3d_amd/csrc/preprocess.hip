@@ -888,15 +888,15 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
   void *sx = nullptr, *sn = nullptr, *sp = nullptr;
   auto cleanup = [&]() {
     for (void *b : {sx, sn, sp})
-      if (b) (void)hipFree(b);
+      if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
     if (mem == O3D_MEM_HOST) {
-      O3D_HIP(ctx, hipMalloc(&sx, bytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sx, bytes));
       O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, bytes));
       d_xyz = (const double *)sx;
       if (!sharded || has_normals) {
-        O3D_HIP(ctx, hipMalloc(&sn, bytes));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sn, bytes));
         if (has_normals) O3D_HIP(ctx, o3d_h2d(ctx, sn, normals, bytes));
         d_nrm = (double *)sn;
       }
@@ -923,7 +923,7 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
       p_hi = std::min<int64_t>(ng, p_lo + rows);
       d_out = out_part;
       if (mem == O3D_MEM_HOST) {
-        O3D_HIP(ctx, hipMalloc(&sp, sizeof(double) * 3 * (size_t)std::max<int64_t>(rows, 1)));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sp, sizeof(double) * 3 * (size_t)std::max<int64_t>(rows, 1)));
         d_out = (double *)sp;
       }
       if (rows > 0) O3D_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(double) * 3 * (size_t)rows, ctx->stream));  // padding rows
@@ -999,13 +999,13 @@ int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t 
   void *sx = nullptr, *sn = nullptr, *sp = nullptr;
   auto cleanup = [&]() {
     for (void *b : {sx, sn, sp})
-      if (b) (void)hipFree(b);
+      if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
     if (mem == O3D_MEM_HOST) {
-      O3D_HIP(ctx, hipMalloc(&sx, bytes));
-      O3D_HIP(ctx, hipMalloc(&sn, bytes));
-      O3D_HIP(ctx, hipMalloc(&sp, pbytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sx, bytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sn, bytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sp, pbytes));
       O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, bytes));
       O3D_HIP(ctx, o3d_h2d(ctx, sp, all_parts, sizeof(double) * 3 * (size_t)(rows * n_shards)));
       d_xyz = (const double *)sx; d_nrm = (double *)sn; d_parts = (const double *)sp;
@@ -1035,23 +1035,23 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
   void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto cleanup = [&]() {
     for (void *p : stage)
-      if (p) (void)hipFree(p);
+      if (p) o3d_tmp_free(ctx, p);
   };
   auto run = [&]() -> int {
     const double *d_xyz = xyz, *d_nrm = nrm, *d_col = col;
     double *o_xyz = out_xyz, *o_nrm = out_nrm, *o_col = out_col;
     int32_t *o_vox = out_vox;
     if (mem == O3D_MEM_HOST) {
-      O3D_HIP(ctx, hipMalloc(&stage[0], bytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[0], bytes));
       O3D_HIP(ctx, o3d_h2d(ctx, stage[0], xyz, bytes));
       d_xyz = (const double *)stage[0];
       if (nrm) {
-        O3D_HIP(ctx, hipMalloc(&stage[1], bytes));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[1], bytes));
         O3D_HIP(ctx, o3d_h2d(ctx, stage[1], nrm, bytes));
         d_nrm = (const double *)stage[1];
       }
       if (col) {
-        O3D_HIP(ctx, hipMalloc(&stage[2], bytes));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[2], bytes));
         O3D_HIP(ctx, o3d_h2d(ctx, stage[2], col, bytes));
         d_col = (const double *)stage[2];
       }
@@ -1106,11 +1106,11 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
                        (const uint32_t *)head, nf, seg_start);
     if (mem == O3D_MEM_HOST) {
       const size_t ob = sizeof(double) * 3 * (size_t)m;
-      O3D_HIP(ctx, hipMalloc(&stage[3], ob));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[3], ob));
       o_xyz = (double *)stage[3];
-      if (nrm) { O3D_HIP(ctx, hipMalloc(&stage[4], ob)); o_nrm = (double *)stage[4]; }
-      if (col) { O3D_HIP(ctx, hipMalloc(&stage[5], ob)); o_col = (double *)stage[5]; }
-      if (out_vox) { O3D_HIP(ctx, hipMalloc(&stage[6], sizeof(int32_t) * 3 * (size_t)m)); o_vox = (int32_t *)stage[6]; }
+      if (nrm) { O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[4], ob)); o_nrm = (double *)stage[4]; }
+      if (col) { O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[5], ob)); o_col = (double *)stage[5]; }
+      if (out_vox) { O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[6], sizeof(int32_t) * 3 * (size_t)m)); o_vox = (int32_t *)stage[6]; }
     }
     hipLaunchKernelGGL(k_voxel_reduce, dim3(grid_for(m)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, d_nrm, d_col, (const uint64_t *)keys,
                        (const uint32_t *)vals, (const uint32_t *)seg_start, m, nf, vp, o_xyz, nrm ? o_nrm : nullptr,
@@ -1172,26 +1172,26 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
   void *sc = nullptr, *sq = nullptr, *so = nullptr;
   const size_t out_bytes = (mode == 2 ? sizeof(int32_t) : sizeof(double)) * (size_t)n_q;
   auto cleanup = [&]() {
-    if (sc) (void)hipFree(sc);
-    if (sq) (void)hipFree(sq);
-    if (so) (void)hipFree(so);
+    if (sc) o3d_tmp_free(ctx, sc);
+    if (sq) o3d_tmp_free(ctx, sq);
+    if (so) o3d_tmp_free(ctx, so);
   };
   auto run = [&]() -> int {
     void *d_out = (mode == 2) ? (void *)out_count : (void *)out;
     if (mem == O3D_MEM_HOST) {
       if (n_cloud > 0) {
-        O3D_HIP(ctx, hipMalloc(&sc, sizeof(double) * 3 * (size_t)n_cloud));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sc, sizeof(double) * 3 * (size_t)n_cloud));
         O3D_HIP(ctx, o3d_h2d(ctx, sc, cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud));
         d_cloud = (const double *)sc;
       }
       if (same) {
         d_q = d_cloud;
       } else {
-        O3D_HIP(ctx, hipMalloc(&sq, sizeof(double) * 3 * (size_t)n_q));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sq, sizeof(double) * 3 * (size_t)n_q));
         O3D_HIP(ctx, o3d_h2d(ctx, sq, q_xyz, sizeof(double) * 3 * (size_t)n_q));
         d_q = (const double *)sq;
       }
-      O3D_HIP(ctx, hipMalloc(&so, out_bytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &so, out_bytes));
       d_out = so;
     }
     double h = radius;
@@ -1244,18 +1244,18 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
   void *sx = nullptr, *sn = nullptr, *so = nullptr, *sp = nullptr;
   auto cleanup = [&]() {
     for (void *b : {sx, sn, so, sp})
-      if (b) (void)hipFree(b);
+      if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
     if (mem == O3D_MEM_HOST) {
-      O3D_HIP(ctx, hipMalloc(&sx, pbytes));
-      O3D_HIP(ctx, hipMalloc(&sn, pbytes));
-      O3D_HIP(ctx, hipMalloc(&so, fbytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sx, pbytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sn, pbytes));
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &so, fbytes));
       O3D_HIP(ctx, o3d_h2d(ctx, sx, xyz, pbytes));
       O3D_HIP(ctx, o3d_h2d(ctx, sn, nrm, pbytes));
       d_xyz = (const double *)sx; d_nrm = (const double *)sn; d_out = (double *)so;
     }
-    O3D_HIP(ctx, hipMalloc(&sp, fbytes));
+    O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sp, fbytes));
     O3D_HIP(ctx, hipMemsetAsync(sp, 0, fbytes, ctx->stream));
     O3D_HIP(ctx, hipMemsetAsync(d_out, 0, fbytes, ctx->stream));
     const bool knn_mode = search_type == O3D_SEARCH_KNN;

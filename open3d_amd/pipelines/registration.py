@@ -101,8 +101,12 @@ class TransformationEstimationPointToPlane(TransformationEstimation):
 
 
 def _pairs(corr):
-    idx = np.nonzero(corr >= 0)[0].astype(np.int32)
-    return np.stack([idx, corr[idx]], axis=1) if len(idx) else np.zeros((0, 2), np.int32)
+    """Dense corr -> (n_corr, 2) pairs, ascending source index (o3d_expand_correspondences: one pass in C; the numpy
+    nonzero / take / stack chain took 10x as long as the whole device-side ICP call on millions of points)."""
+    corr = np.ascontiguousarray(corr, dtype=np.int32)
+    out = np.empty((len(corr), 2), np.int32)
+    m = _lib.load().o3d_expand_correspondences(corr.ctypes.data, len(corr), out.ctypes.data) if len(corr) else 0
+    return out[:m]
 
 
 def RegistrationICP(source, target, max_correspondence_distance, init=None, estimation=None, criteria=None, ctx=None):
