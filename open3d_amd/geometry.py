@@ -75,14 +75,15 @@ class PointCloud:
         op = np.empty((max(n, 1), 3))
         on = np.empty((max(n, 1), 3)) if nrm is not None else None
         oc = np.empty((max(n, 1), 3)) if col is not None else None
-        ov = np.empty((max(n, 1), 3), np.int32)
+        ov = np.empty((max(n, 1), 3), np.int32) if return_voxel_index else None
         m = C.c_int64()
         ctx.check(ctx._lib.o3d_voxel_down_sample(ctx.handle, _lib.ptr(self.points_), _lib.ptr(nrm), _lib.ptr(col), n,
                                                  float(voxel_size), _lib.MEM_HOST, _lib.ptr(op), _lib.ptr(on), _lib.ptr(oc),
                                                  _lib.ptr(ov), C.byref(m)))
         m = m.value
-        out = PointCloud(op[:m].copy(), on[:m].copy() if on is not None else None, oc[:m].copy() if oc is not None else None)
-        return (out, ov[:m].copy()) if return_voxel_index else out
+        # (prefix views, no copies: the untouched tail of the np.empty buffers never becomes resident)
+        out = PointCloud(op[:m], on[:m] if on is not None else None, oc[:m] if oc is not None else None)
+        return (out, ov[:m]) if return_voxel_index else out
 
     def EstimateNormals(self, search_param=None, fast_normal_computation=True, ctx=None):
         """PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351."""
