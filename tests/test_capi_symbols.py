@@ -45,3 +45,23 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_expand_correspondences_host_helper():
+    """o3d_expand_correspondences is host-only: dense corr -> (source, target) pairs in ascending source index."""
+    import ctypes as C
+    import numpy as np
+    from open3d_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    corr = rng.integers(-1, 50, 1000).astype(np.int32)
+    corr[rng.random(1000) < 0.3] = -1
+    out = np.full((1000, 2), -7, np.int32)
+    m = lib.o3d_expand_correspondences(corr.ctypes.data, len(corr), out.ctypes.data)
+    idx = np.nonzero(corr >= 0)[0]
+    assert m == len(idx)
+    assert np.array_equal(out[:m, 0], idx) and np.array_equal(out[:m, 1], corr[idx])
+    assert (out[m:] == -7).all()
+    assert lib.o3d_expand_correspondences(corr.ctypes.data, 0, out.ctypes.data) == 0
+    none = np.full(8, -1, np.int32)
+    assert lib.o3d_expand_correspondences(none.ctypes.data, 8, out.ctypes.data) == 0
