@@ -5,6 +5,8 @@
 
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "o3d_internal.h"
 
 namespace {
@@ -754,23 +756,30 @@ __device__ __forceinline__ int fpfh_bin(double v) {
 }
 
 // PASS 0: ComputeSPFHFeature (Feature.cpp:71-111) -> spfh[33 * i + j].  PASS 1: the weighting of ComputeFPFHFeature
-// (:127-157) -> out[33 * i + j], reading spfh.  Both search the neighbours again, like the reference.  Features are 33
-// doubles per point (Feature::data_ is a column-major 33 x n Eigen matrix), in the caller's point order.
+// (:127-157) -> out[33 * i + j], reading spfh.  The reference searches the neighbours again in the second pass; here pass 0
+// leaves them behind (index and distance of neighbour k of the point at position p at [k * n_grid + p], the count at
+// nbr_cnt[p]) when the host found room for that table (nbr_cnt != nullptr), and pass 1 then needs neither a search nor LDS.
+// Features are 33 doubles per point (Feature::data_ is a column-major 33 x n Eigen matrix), in the caller's point order.
 template <int PASS>
 __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ pts, int64_t n_grid, const uint32_t *__restrict__ cell_start,
                                                      GridParams gp, int knn, double thr, int knn_mode, const double *__restrict__ normals,
-                                                     const double *__restrict__ spfh, double *__restrict__ out) {
+                                                     const double *__restrict__ spfh, double *__restrict__ out,
+                                                     uint32_t *__restrict__ nbr_idx, double *__restrict__ nbr_d2,
+                                                     int32_t *__restrict__ nbr_cnt) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
+  const bool cached = nbr_cnt != nullptr;
   KList l;
   klist_bind(l, smem, lane, knn, pts);
   l.thr = knn_mode ? INFINITY : thr;
+  l.count = 0;
   for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
     const double4 q = pts[p];
     const size_t qi = (size_t)__double_as_longlong(q.w);
-    collect_neighbors(l, pts, cell_start, gp, q.x, q.y, q.z, knn_mode != 0);
+    if (PASS == 0 || !cached) collect_neighbors(l, pts, cell_start, gp, q.x, q.y, q.z, knn_mode != 0);
     double *o = out + 33 * qi;
     if (PASS == 0) {
+      if (cached) nbr_cnt[p] = l.count;
       // the row was zeroed by the host; one lane owns it
       if (l.count > 1) {
         const double hist_incr = 100.0 / (double)(l.count - 1);
@@ -779,6 +788,10 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
         for (int k = 1; k < l.count; k++) {
           const double4 t = pts[l.pos[k * kNrmBlock]];
           const size_t ti = (size_t)__double_as_longlong(t.w);
+          if (cached) {
+            nbr_idx[(size_t)k * (size_t)n_grid + (size_t)p] = (uint32_t)ti;
+            nbr_d2[(size_t)k * (size_t)n_grid + (size_t)p] = l.d2[k * kNrmBlock];
+          }
           const double p2[3] = {t.x, t.y, t.z};
           const double n2[3] = {normals[3 * ti], normals[3 * ti + 1], normals[3 * ti + 2]};
           double f[4];
@@ -788,24 +801,40 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
           o[fpfh_bin(11 * (f[2] + 1.0) * 0.5) + 22] += hist_incr;
         }
       }
-    } else if (l.count > 1) {
-      double sum[3] = {0.0, 0.0, 0.0};
-      for (int k = 1; k < l.count; k++) {
-        const double dist = l.d2[k * kNrmBlock];
-        if (dist == 0.0) continue;
-        const double *sp = spfh + 33 * (size_t)kl_index(l, l.pos[k * kNrmBlock]);
-        for (int j = 0; j < 33; j++) {
-          const double val = sp[j] / dist;
-          sum[j / 11] += val;
-          o[j] += val;
+    } else {
+      const int cnt = cached ? nbr_cnt[p] : l.count;
+      if (cnt > 1) {
+        double acc[33], sum[3] = {0.0, 0.0, 0.0};  // (the row was zeroed by the host: the same additions, in registers)
+#pragma unroll
+        for (int j = 0; j < 33; j++) acc[j] = 0.0;
+        for (int k = 1; k < cnt; k++) {
+          double dist;
+          size_t ni;
+          if (cached) {
+            dist = nbr_d2[(size_t)k * (size_t)n_grid + (size_t)p];
+            ni = nbr_idx[(size_t)k * (size_t)n_grid + (size_t)p];
+          } else {
+            dist = l.d2[k * kNrmBlock];
+            ni = kl_index(l, l.pos[k * kNrmBlock]);
+          }
+          if (dist == 0.0) continue;
+          const double *sp = spfh + 33 * ni;
+#pragma unroll
+          for (int j = 0; j < 33; j++) {
+            const double val = sp[j] / dist;
+            sum[j / 11] += val;
+            acc[j] += val;
+          }
         }
-      }
-      for (int j = 0; j < 3; j++)
-        if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
-      const double *self = spfh + 33 * qi;
-      for (int j = 0; j < 33; j++) {
-        o[j] *= sum[j / 11];
-        o[j] += self[j];
+        for (int j = 0; j < 3; j++)
+          if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+        const double *self = spfh + 33 * qi;
+#pragma unroll
+        for (int j = 0; j < 33; j++) {
+          double v = acc[j] * sum[j / 11];
+          v += self[j];
+          o[j] = v;
+        }
       }
     }
   }
@@ -1241,9 +1270,9 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
   const size_t pbytes = sizeof(double) * 3 * (size_t)n, fbytes = sizeof(double) * 33 * (size_t)n;
   const double *d_xyz = xyz, *d_nrm = nrm;
   double *d_out = out_feature;
-  void *sx = nullptr, *sn = nullptr, *so = nullptr, *sp = nullptr;
+  void *sx = nullptr, *sn = nullptr, *so = nullptr, *sp = nullptr, *sd = nullptr, *si = nullptr, *sc = nullptr;
   auto cleanup = [&]() {
-    for (void *b : {sx, sn, so, sp})
+    for (void *b : {sx, sn, so, sp, sd, si, sc})
       if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
@@ -1273,12 +1302,24 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
       const size_t lds = kListEntryBytes * kNrmBlock * (size_t)knn;
       int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
       g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+      // the neighbour table between the passes: 12 B per neighbour slot, kept when it is at most 8 GiB
+      const size_t slots = (size_t)ng * (size_t)knn;
+      uint32_t *nbr_idx = nullptr;
+      double *nbr_d2 = nullptr;
+      int32_t *nbr_cnt = nullptr;
+      if (slots * 12 <= ((size_t)8 << 30) && !getenv("O3D_FPFH_NO_TABLE")) {  // (the switch: both paths are tested)
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sd, sizeof(double) * slots));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &si, sizeof(uint32_t) * slots));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sc, sizeof(int32_t) * (size_t)ng));
+        nbr_d2 = (double *)sd; nbr_idx = (uint32_t *)si; nbr_cnt = (int32_t *)sc;
+      }
       O3D_TRY(allow_lds(ctx, k_fpfh<0>, lds));
       hipLaunchKernelGGL(k_fpfh<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
-                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)nullptr, (double *)sp);
-      O3D_TRY(allow_lds(ctx, k_fpfh<1>, lds));
-      hipLaunchKernelGGL(k_fpfh<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
-                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)sp, d_out);
+                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)nullptr, (double *)sp, nbr_idx, nbr_d2, nbr_cnt);
+      const size_t lds1 = nbr_cnt ? 0 : lds;
+      O3D_TRY(allow_lds(ctx, k_fpfh<1>, lds1));
+      hipLaunchKernelGGL(k_fpfh<1>, dim3((int)g), dim3(kNrmBlock), lds1, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp, knn,
+                         thr, knn_mode ? 1 : 0, d_nrm, (const double *)sp, d_out, nbr_idx, nbr_d2, nbr_cnt);
       O3D_HIP(ctx, hipGetLastError());
     }
     if (mem == O3D_MEM_HOST) O3D_HIP(ctx, o3d_d2h(ctx, out_feature, d_out, fbytes));

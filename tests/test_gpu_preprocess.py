@@ -230,6 +230,23 @@ def test_fpfh_matches_oracle(ctx, oracle, mode):
     assert bad.sum() <= max(3, len(pts) // 2000), "too many points differ: %d" % bad.sum()
 
 
+def test_fpfh_second_pass_with_and_without_neighbour_table(ctx, monkeypatch):
+    """Pass 1 of ComputeFPFHFeature reads the neighbours pass 0 left behind, or (table too large / switched off) searches
+    them again: the two routes must give the same bits."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(100, 15000, cfg_id=36)
+    s, pts = sc["spacing"], sc["target"]
+    pc = geometry.PointCloud(pts)
+    pc.EstimateNormals(geometry.KDTreeSearchParamHybrid(4 * s, 30), ctx=ctx)
+    for sp in (geometry.KDTreeSearchParamHybrid(6 * s, 50), geometry.KDTreeSearchParamKNN(20)):
+        monkeypatch.delenv("O3D_FPFH_NO_TABLE", raising=False)
+        a = reg.ComputeFPFHFeature(pc, sp, ctx=ctx).data_
+        monkeypatch.setenv("O3D_FPFH_NO_TABLE", "1")
+        b = reg.ComputeFPFHFeature(pc, sp, ctx=ctx).data_
+        assert np.array_equal(a, b) and a.any()
+
+
 def test_large_neighbourhoods_up_to_128(ctx, oracle):
     """max_nn = 100 (the usual FPFH parameter, Hybrid(5 voxels, 100)) and knn = 128: lists beyond 64 KiB of LDS."""
     from open3d_amd import geometry, _lib
