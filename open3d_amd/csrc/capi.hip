@@ -1167,7 +1167,10 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
   O3D_TRY(b.in(ctx, src_feature, (size_t)dim * (size_t)n_src, mem, &d_sf));
   O3D_TRY(b.in(ctx, tgt_feature, (size_t)dim * (size_t)n_tgt, mem, &d_tf));
 
-  const int kBatch = 256;
+  // Hypotheses per round trip: 256 to begin with, doubled (up to kBatch) after every batch in which the checkers let
+  // nothing through -- such a batch costs one small kernel and two host round trips, whatever its size.
+  const int kBatch = 4096;
+  int batch = 256;
   // similar_features (:215, :235-242): the feature-space nearest neighbour of a source point, found when it is first
   // sampled.  When the loop can sample most of the cloud anyway, all of them are found in one launch up front.
   std::vector<int32_t> nn((size_t)n_src, -2);
@@ -1212,7 +1215,7 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
 
   auto run = [&]() -> int {
     while (itr < max_iteration && validations < max_validation) {
-      const int nb = std::min(kBatch, max_iteration - itr);
+      const int nb = std::min(batch, max_iteration - itr);
       const size_t nid = (size_t)nb * (size_t)ransac_n;
       for (size_t k = 0; k < nid; k++) ids[k] = pick(rng);  // :234
       if (!all_up_front) {
@@ -1236,9 +1239,10 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
       O3D_HIP(ctx, o3d_d2h(ctx, Ts.data(), d_T, sizeof(double) * 16 * (size_t)nb));
       O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
       // validation (:269-284) of the hypotheses that passed, in iteration order, until max_validation is reached
-      int nv = 0;
+      int nv = 0, used = nb;  // used: iterations of this batch the reference's loop would have run (:230)
       std::vector<int> which;
-      for (int k = 0; k < nb && validations + nv < max_validation; k++) {
+      for (int k = 0; k < nb; k++) {
+        if (validations + nv >= max_validation) { used = k; break; }
         if (!ok[k]) continue;
         O3D_TRY(o3d_launch_set_hypothesis(ctx, Ts.data() + 16 * (size_t)k));
         O3D_TRY(o3d_icp_pass_to(ctx, (double *)d_all + (size_t)nv * O3D_NSUMS));
@@ -1259,7 +1263,8 @@ int o3d_registration_ransac_feature_matching(o3d_ctx *ctx, const double *src_xyz
         }
         validations += nv;
       }
-      itr += nb;
+      itr += used;
+      if (nv == 0) batch = std::min(2 * batch, kBatch);
     }
     if (out_T) memcpy(out_T, bestT, sizeof(bestT));
     if (out_n_corr) *out_n_corr = bnc;
