@@ -155,6 +155,7 @@ def test_ransac_edge_cases(ctx):
     res = reg.RegistrationRANSACBasedOnFeatureMatching(ps, pt, f, f, 0.5, None, 3, None, reg.RANSACConvergenceCriteria(20, 7), seed=1,
                                                        ctx=ctx)
     assert res.validations_ == 7
+    assert res.iterations_ == 7   # no checkers: every iteration validates, the loop condition (:230) stops it after seven
 
 
 def test_ransac_based_on_correspondence(ctx, oracle):
