@@ -67,7 +67,15 @@ int o3d_reserve(o3d_ctx *ctx, void **ptr, size_t *cap, size_t bytes) {
     *cap = 0;
   }
   size_t want = bytes < 256 ? 256 : bytes;
-  O3D_HIP(ctx, hipMalloc(ptr, want));
+  hipError_t e = hipMalloc(ptr, want);
+  if (e == hipErrorOutOfMemory && !ctx->tmp_idle.empty()) {  // the idle per-call blocks go first
+    (void)hipGetLastError();
+    for (const o3d_ctx::TmpBlock &b : ctx->tmp_idle) (void)hipFree(b.p);
+    ctx->tmp_idle.clear();
+    ctx->tmp_idle_bytes = 0;
+    e = hipMalloc(ptr, want);
+  }
+  O3D_HIP(ctx, e);
   *cap = want;
   return O3D_OK;
 }
