@@ -225,7 +225,7 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
 constexpr int kNrmLoads = 12;  // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
-constexpr int kMaxKnn = 128;  // 12 B per list entry and lane: 96 KiB of the CU's 160 KiB LDS for one wavefront
+constexpr int kMaxKnn = 128;  // 8 B per list entry and lane: 64 KiB of the CU's 160 KiB LDS for one wavefront
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel.
 template <typename K>
@@ -238,87 +238,125 @@ int allow_lds(o3d_ctx *ctx, K kernel, size_t lds) {
 // k-best list of one lane.  While candidates arrive it is a binary MAX-heap on (d2, index) -- the worst kept entry is the
 // root, an insertion moves at most log2(k) entries (a sorted list moves k/2 on average and, lanes inserting at different
 // places, nearly k per wavefront step) -- and klist_sort turns it in place into the ascending order FLANN returns and
-// ComputeNormal sums in.  An entry is 12 bytes of LDS, distance and position: the original index, which only breaks ties
-// between equal distances, is read back from the cloud (pts[pos].w) when two distances ARE equal.  The lists are what
-// limits the wavefronts per CU, and a third array for the index cost a quarter of them.
+// ComputeNormal sums in.  The lists are what limits the wavefronts per CU, so an entry is 8 bytes of LDS: the distance
+// ROUNDED TO FLOAT and the position in the cell-ordered cloud.  Rounding is monotone, so two different keys order their
+// entries exactly as the fp64 distances would; two EQUAL keys say nothing, and then -- only then -- both distances are
+// recomputed in fp64 from the cloud and the query (the arithmetic of the visit: ((qx-x)^2 + (qy-y)^2) + (qz-z)^2) and
+// ties between those go to the lower original index (pts[pos].w).  The kept set and its order are the exact ones.
 struct KList {
-  double *d2;     // LDS, stride kNrmBlock
+  float *key;     // LDS, stride kNrmBlock: (float)d2
   uint32_t *pos;  // LDS, stride kNrmBlock: position in the cell-ordered cloud
   const double4 *pts;  // the cell-ordered cloud (w = original index)
+  double qx, qy, qz;   // the query
   int cap, count;
   double thr;     // strict bound on d2 (INFINITY for pure KNN)
 };
-constexpr size_t kListEntryBytes = sizeof(double) + sizeof(uint32_t);
+constexpr size_t kListEntryBytes = sizeof(float) + sizeof(uint32_t);
 
 __device__ __forceinline__ void klist_bind(KList &l, unsigned char *smem, int lane, int knn, const double4 *pts) {
-  l.d2 = reinterpret_cast<double *>(smem) + lane;
-  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(double) * kNrmBlock * (size_t)knn) + lane;
+  l.key = reinterpret_cast<float *>(smem) + lane;
+  l.pos = reinterpret_cast<uint32_t *>(smem + sizeof(float) * kNrmBlock * (size_t)knn) + lane;
   l.pts = pts;
   l.cap = knn;
+}
+__device__ __forceinline__ void klist_query(KList &l, double qx, double qy, double qz) {
+  l.qx = qx; l.qy = qy; l.qz = qz;
+  l.count = 0;
 }
 
 __device__ __forceinline__ uint32_t kl_index(const KList &l, uint32_t pos) {
   return (uint32_t)__double_as_longlong(l.pts[pos].w);
 }
-// (d1, index of p1) < (d2, index of p2); the indices are looked up for equal distances only
-__device__ __forceinline__ bool kl_less(const KList &l, double d1, uint32_t p1, double d2, uint32_t p2) {
-  if (d1 != d2) return d1 < d2;
-  return kl_index(l, p1) < kl_index(l, p2);
+// the fp64 distance of the entry at `pos`, as the visit computed it
+__device__ __forceinline__ double kl_exact(const KList &l, uint32_t pos, uint32_t *idx = nullptr) {
+  const double4 t = l.pts[pos];
+  const double ddx = l.qx - t.x, ddy = l.qy - t.y, ddz = l.qz - t.z;
+  double d2 = ddx * ddx;
+  d2 = d2 + ddy * ddy;
+  d2 = d2 + ddz * ddz;
+  if (idx) *idx = (uint32_t)__double_as_longlong(t.w);
+  return d2;
+}
+// entry 1 < entry 2 in (d2, index) order.  The equal-key path is rare and kept out of line: inlined at every comparison of
+// the heap code it pushed the kernels into scratch memory.
+__device__ __noinline__ bool kl_less_exact(const double4 *pts, double qx, double qy, double qz, uint32_t p1, uint32_t p2) {
+  const double4 a = pts[p1], b = pts[p2];
+  double ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
+  double e1 = ax * ax;
+  e1 = e1 + ay * ay;
+  e1 = e1 + az * az;
+  double bx = qx - b.x, by = qy - b.y, bz = qz - b.z;
+  double e2 = bx * bx;
+  e2 = e2 + by * by;
+  e2 = e2 + bz * bz;
+  return e1 < e2 || (e1 == e2 && (uint32_t)__double_as_longlong(a.w) < (uint32_t)__double_as_longlong(b.w));
+}
+__device__ __forceinline__ bool kl_less(const KList &l, float k1, uint32_t p1, float k2, uint32_t p2) {
+  if (k1 != k2) return k1 < k2;
+  if (p1 == p2) return false;
+  return kl_less_exact(l.pts, l.qx, l.qy, l.qz, p1, p2);
 }
 
-__device__ __forceinline__ double klist_worst(const KList &l) {
-  return (l.count == l.cap) ? l.d2[0] : l.thr;
+// Can a candidate at distance d2 still enter the list?  (No: it is farther than the worst kept entry -- a larger key
+// means a larger distance -- or outside the radius.  Yes may still be refused by klist_add when the keys are equal.)
+__device__ __forceinline__ bool klist_may_take(const KList &l, double d2) {
+  return d2 < l.thr && (l.count < l.cap || (float)d2 <= l.key[0]);
+}
+// An upper bound of the k-th distance of a full list (the key may have been rounded down by half an ulp).
+__device__ __forceinline__ double klist_kth_upper(const KList &l) {
+  return (double)nextafterf(l.key[0], INFINITY);
 }
 
-// Put (d, pos) into the hole at the root of the heap of `n` entries and let it sink.
-__device__ __forceinline__ void klist_sink(KList &l, int n, double d, uint32_t pos) {
+// Put (key, pos) into the hole at the root of the heap of `n` entries and let it sink.
+__device__ __forceinline__ void klist_sink(KList &l, int n, float d, uint32_t pos) {
   int i = 0;
   for (;;) {
     int c = 2 * i + 1;
     if (c >= n) break;
-    double cd = l.d2[c * kNrmBlock];
+    float cd = l.key[c * kNrmBlock];
     uint32_t cp = l.pos[c * kNrmBlock];
     if (c + 1 < n) {
-      const double rd = l.d2[(c + 1) * kNrmBlock];
+      const float rd = l.key[(c + 1) * kNrmBlock];
       const uint32_t rp = l.pos[(c + 1) * kNrmBlock];
       if (kl_less(l, cd, cp, rd, rp)) { c++; cd = rd; cp = rp; }
     }
     if (!kl_less(l, d, pos, cd, cp)) break;
-    l.d2[i * kNrmBlock] = cd;
+    l.key[i * kNrmBlock] = cd;
     l.pos[i * kNrmBlock] = cp;
     i = c;
   }
-  l.d2[i * kNrmBlock] = d;
+  l.key[i * kNrmBlock] = d;
   l.pos[i * kNrmBlock] = pos;
 }
 
-__device__ __forceinline__ void klist_add(KList &l, double d, uint32_t pos) {
-  if (!(d < l.thr)) return;
+__device__ __forceinline__ void klist_add(KList &l, double d2, uint32_t pos) {
+  if (!(d2 < l.thr)) return;
+  const float d = (float)d2;
   if (l.count == l.cap) {  // replace the worst entry if the candidate is better
-    if (!kl_less(l, d, pos, l.d2[0], l.pos[0])) return;
+    if (!kl_less(l, d, pos, l.key[0], l.pos[0])) return;
     klist_sink(l, l.cap, d, pos);
     return;
   }
   int i = l.count++;
   while (i > 0) {  // rise
     const int p = (i - 1) >> 1;
-    const double pd = l.d2[p * kNrmBlock];
+    const float pd = l.key[p * kNrmBlock];
     const uint32_t pp = l.pos[p * kNrmBlock];
     if (!kl_less(l, pd, pp, d, pos)) break;
-    l.d2[i * kNrmBlock] = pd;
+    l.key[i * kNrmBlock] = pd;
     l.pos[i * kNrmBlock] = pp;
     i = p;
   }
-  l.d2[i * kNrmBlock] = d;
+  l.key[i * kNrmBlock] = d;
   l.pos[i * kNrmBlock] = pos;
 }
 
 // Heap -> ascending by (d2, index), in place.  Call once, after the last klist_add and before reading the entries in order.
 __device__ __forceinline__ void klist_sort(KList &l) {
   for (int end = l.count - 1; end > 0; end--) {
-    const double d = l.d2[end * kNrmBlock];
+    const float d = l.key[end * kNrmBlock];
     const uint32_t pos = l.pos[end * kNrmBlock];
-    l.d2[end * kNrmBlock] = l.d2[0];
+    l.key[end * kNrmBlock] = l.key[0];
     l.pos[end * kNrmBlock] = l.pos[0];
     klist_sink(l, end, d, pos);
   }
@@ -434,7 +472,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
     const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    l.count = 0;
+    klist_query(l, q.x, q.y, q.z);
     int count = 0;                                  // MODE 1
     double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // cumulants
     auto visit = [&](const double4 &t, uint32_t j, bool real) {
@@ -450,7 +488,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
           c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
           c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
         }
-      } else if (d2 <= klist_worst(l)) {
+      } else if (klist_may_take(l, d2)) {
         klist_add(l, d2, j);
       }
     };
@@ -461,7 +499,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
       if (R >= max_dim) break;
       if (l.count == l.cap) {
         const double reach = (double)R * gp.h * (1.0 - 1e-6);
-        if (klist_worst(l) <= reach * reach) break;
+        if (klist_kth_upper(l) <= reach * reach) break;
       }
     }
     int k = count;
@@ -587,13 +625,13 @@ __global__ __launch_bounds__(kNrmBlock) void k_color_gradient(const double4 *__r
     const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    l.count = 0;
+    klist_query(l, q.x, q.y, q.z);
     walk_block3(pts, cell_start, gp, cx, cy, cz, (uint32_t)p, [&](const double4 &t, uint32_t j, bool real) {
       const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
       double d2 = ddx * ddx;
       d2 = d2 + ddy * ddy;
       d2 = d2 + ddz * ddz;
-      if (real && d2 <= klist_worst(l)) klist_add(l, d2, j);
+      if (real && klist_may_take(l, d2)) klist_add(l, d2, j);
     });
     double g[3] = {0.0, 0.0, 0.0};
     klist_sort(l);
@@ -648,7 +686,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
     const int cx = min(max(o3d_cell_coord(qx, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     const int cy = min(max(o3d_cell_coord(qy, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    l.count = 0;
+    klist_query(l, qx, qy, qz);
     int count = 0;
     auto visit = [&](const double4 &t, uint32_t j, bool real) {
       const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
@@ -658,7 +696,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
       if (!real) return;
       if (MODE == 2) {
         if (d2 < thr) count++;
-      } else if (d2 <= klist_worst(l)) {
+      } else if (klist_may_take(l, d2)) {
         klist_add(l, d2, j);
       }
     };
@@ -669,17 +707,17 @@ __global__ __launch_bounds__(kNrmBlock) void k_neighbor_query(const double4 *__r
       if (R >= max_dim) break;
       if (l.count == l.cap) {
         const double reach = (double)R * gp.h * (1.0 - 1e-6);
-        if (klist_worst(l) <= reach * reach) break;
+        if (klist_kth_upper(l) <= reach * reach) break;
       }
     }
     if (MODE == 0) {  // the k-th distance is the worst kept entry: the heap's root
-      out[i] = (l.count >= knn) ? sqrt(l.d2[0]) : 0.0;
+      out[i] = (l.count >= knn) ? sqrt(kl_exact(l, l.pos[0])) : 0.0;
     } else if (MODE == 1) {
       double mean = -1.0;
       if (l.count > 0) {
         klist_sort(l);
         double sum = 0.0;  // std::accumulate over the ascending distances (PointCloud.cpp:445-446)
-        for (int k = 0; k < l.count; k++) sum += sqrt(l.d2[k * kNrmBlock]);
+        for (int k = 0; k < l.count; k++) sum += sqrt(kl_exact(l, l.pos[k * kNrmBlock]));
         mean = sum / (double)l.count;
       }
       out[i] = mean;
@@ -700,13 +738,13 @@ __device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__res
   const int cy = min(max(o3d_cell_coord(qy, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
   const int cz = min(max(o3d_cell_coord(qz, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
-  l.count = 0;
+  klist_query(l, qx, qy, qz);
   auto visit = [&](const double4 &t, uint32_t j, bool real) {
     const double ddx = qx - t.x, ddy = qy - t.y, ddz = qz - t.z;
     double d2 = ddx * ddx;
     d2 = d2 + ddy * ddy;
     d2 = d2 + ddz * ddz;
-    if (real && d2 <= klist_worst(l)) klist_add(l, d2, j);
+    if (real && klist_may_take(l, d2)) klist_add(l, d2, j);
   };
   for (int R = 1;; R++) {
     if (R == 1) walk_block3(pts, cell_start, gp, cx, cy, cz, 0u, visit);
@@ -715,7 +753,7 @@ __device__ __forceinline__ void collect_neighbors(KList &l, const double4 *__res
     if (R >= max_dim) break;
     if (l.count == l.cap) {
       const double reach = (double)R * gp.h * (1.0 - 1e-6);
-      if (klist_worst(l) <= reach * reach) break;
+      if (klist_kth_upper(l) <= reach * reach) break;
     }
   }
   klist_sort(l);
@@ -790,7 +828,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
           const size_t ti = (size_t)__double_as_longlong(t.w);
           if (cached) {
             nbr_idx[(size_t)k * (size_t)n_grid + (size_t)p] = (uint32_t)ti;
-            nbr_d2[(size_t)k * (size_t)n_grid + (size_t)p] = l.d2[k * kNrmBlock];
+            nbr_d2[(size_t)k * (size_t)n_grid + (size_t)p] = kl_exact(l, l.pos[k * kNrmBlock]);
           }
           const double p2[3] = {t.x, t.y, t.z};
           const double n2[3] = {normals[3 * ti], normals[3 * ti + 1], normals[3 * ti + 2]};
@@ -814,7 +852,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
             dist = nbr_d2[(size_t)k * (size_t)n_grid + (size_t)p];
             ni = nbr_idx[(size_t)k * (size_t)n_grid + (size_t)p];
           } else {
-            dist = l.d2[k * kNrmBlock];
+            dist = kl_exact(l, l.pos[k * kNrmBlock]);
             ni = kl_index(l, l.pos[k * kNrmBlock]);
           }
           if (dist == 0.0) continue;
