@@ -290,7 +290,7 @@ __device__ __forceinline__ uint64_t hilbert3(uint32_t x0, uint32_t x1, uint32_t 
 // grid.  Only the processing ORDER depends on it -- consecutive points form compact patches of cells, which is what
 // the tile pass stages into LDS; results are scattered back by original index.
 __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            const double *__restrict__ T, int apply, int bits,
+                                                            const double *__restrict__ T, int apply, int bits, int drop,
                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restr
     int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    keys[i] = hilbert3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bits);
+    keys[i] = hilbert3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bits) >> drop;
     vals[i] = (uint32_t)i;
   }
 }
@@ -469,10 +469,14 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   const int g = grid_for(n);
   int axis_bits = ceil_log2((uint64_t)std::max(std::max(ctx->gp.nx, ctx->gp.ny), ctx->gp.nz));
   axis_bits = std::min(std::max(axis_bits, 1), 21);
+  // One or two key bits over a multiple of the 8-bit digit would cost a whole radix pass: they are dropped (two or four
+  // neighbouring cells of the curve share a key and keep their given order; only the processing ORDER depends on the key).
+  const int over = (3 * axis_bits) % 8;
+  const int drop = (3 * axis_bits > 8 && over >= 1 && over <= 2) ? over : 0;
   hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, (const double *)dT,
-                     apply_init, axis_bits, (uint64_t *)keys, ctx->src_perm);
+                     apply_init, axis_bits, drop, (uint64_t *)keys, ctx->src_perm);
   O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, ctx->src_perm, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
-                             3 * axis_bits));
+                             3 * axis_bits - drop));
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
                      ctx->src_sorted);
   O3D_HIP(ctx, hipGetLastError());

@@ -71,6 +71,10 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
                                                              uint32_t ntiles) {
   __shared__ uint32_t wcnt[kWaves][256];  // per-wave digit counters, then exclusive-over-waves offsets
   __shared__ uint32_t gbase[256];
+  __shared__ uint32_t dbase[256];         // first place of a digit in the tile's own sorted order
+  __shared__ uint32_t wtot[kWaves];
+  __shared__ KeyT skey[kSortTile];        // the tile in digit order: neighbouring lanes then write neighbouring words
+  __shared__ uint32_t sval[kSortTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) wcnt[w][threadIdx.x] = 0;
@@ -93,13 +97,14 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
 
   const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * (O3D_WAVE * kSortItems);
   KeyT k[kSortItems];
-  uint32_t rank[kSortItems];
+  uint32_t rank[kSortItems], v[kSortItems];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int it = 0; it < kSortItems; it++) {
     const int64_t i = wbase + it * O3D_WAVE + lane;
     const bool valid = i < n;
     k[it] = valid ? keys[i] : (KeyT)0;
+    v[it] = valid ? vals[i] : 0u;
     const uint32_t d = (uint32_t)(k[it] >> shift) & 255u;
     // lanes of this row holding the same digit (wave64 match-any by 8 ballots); invalid lanes match nobody
     uint64_t peers = __ballot(valid);
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
     rank[it] = before + (uint32_t)__popcll(peers & lt_mask);
   }
   __syncthreads();
-  {  // exclusive prefix over the four waves, per digit (thread t owns digit t)
+  {  // exclusive prefix over the four waves, per digit (thread t owns digit t), and over the digits of the tile
     uint32_t run = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; w++) {
@@ -126,16 +131,35 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
       wcnt[w][threadIdx.x] = run;
       run += c;
     }
+    uint32_t all;
+    dbase[threadIdx.x] = block_exclusive_scan(run, wtot, &all);  // (ends with a workgroup barrier)
   }
   __syncthreads();
+  // Straight from the registers, neighbouring lanes would write to 64 different digit segments of the output (a pass over
+  // the low digits of unordered keys ran at a quarter of the speed of one over already ordered digits).  The tile is put
+  // into digit order in LDS first; a digit's run then leaves as consecutive words.
 #pragma unroll
   for (int it = 0; it < kSortItems; it++) {
     const int64_t i = wbase + it * O3D_WAVE + lane;
     if (i < n) {
       const uint32_t d = (uint32_t)(k[it] >> shift) & 255u;
-      const uint32_t pos = gbase[d] + wcnt[wave][d] + rank[it];
-      out_keys[pos] = k[it];
-      out_vals[pos] = vals[i];
+      const uint32_t lp = dbase[d] + wcnt[wave][d] + rank[it];
+      skey[lp] = k[it];
+      sval[lp] = v[it];
+    }
+  }
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+  const uint32_t count = (uint32_t)(n - tile0 < (int64_t)kSortTile ? n - tile0 : (int64_t)kSortTile);
+#pragma unroll
+  for (int it = 0; it < kSortItems; it++) {
+    const uint32_t j = (uint32_t)it * O3D_BLOCK + threadIdx.x;
+    if (j < count) {
+      const KeyT key = skey[j];
+      const uint32_t d = (uint32_t)(key >> shift) & 255u;
+      const uint32_t pos = gbase[d] + (j - dbase[d]);
+      out_keys[pos] = key;
+      out_vals[pos] = sval[j];
     }
   }
 }
