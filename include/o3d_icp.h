@@ -258,7 +258,7 @@ O3D_API int o3d_estimate_normals_assemble(o3d_ctx *ctx, const double *xyz, int64
                                           double *normals);
 
 /* ComputeFPFHFeature, pipelines/registration/Feature.cpp:113-159 (SPFH :71-111, pair features :39-69).  search_type KNN
- * or HYBRID (knn / max_nn <= 128).  out_feature: 33 doubles per point, the storage of Feature::data_ (33 x n, column-major). */
+ * or HYBRID (knn / max_nn <= 256).  out_feature: 33 doubles per point, the storage of Feature::data_ (33 x n, column-major). */
 O3D_API int o3d_compute_fpfh_feature(o3d_ctx *ctx, const double *xyz, const double *normals, int64_t n, int search_type, int knn,
                              double radius, int mem, double *out_feature);
 

@@ -225,7 +225,7 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
 
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
 constexpr int kNrmLoads = 12;  // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
-constexpr int kMaxKnn = 128;  // 8 B per list entry and lane: 64 KiB of the CU's 160 KiB LDS for one wavefront
+constexpr int kMaxKnn = 256;  // 8 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel.
 template <typename K>

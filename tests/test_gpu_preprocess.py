@@ -247,8 +247,8 @@ def test_fpfh_second_pass_with_and_without_neighbour_table(ctx, monkeypatch):
         assert np.array_equal(a, b) and a.any()
 
 
-def test_large_neighbourhoods_up_to_128(ctx, oracle):
-    """max_nn = 100 (the usual FPFH parameter, Hybrid(5 voxels, 100)) and knn = 128: lists beyond 64 KiB of LDS."""
+def test_large_neighbourhoods_up_to_256(ctx, oracle):
+    """max_nn = 100 (the usual FPFH parameter, Hybrid(5 voxels, 100)) and knn = 128 / 256: lists up to 128 KiB of LDS."""
     from open3d_amd import geometry, _lib
     from open3d_amd.pipelines import registration as reg
     sc = make_scene(100, 6000, cfg_id=35)
@@ -260,10 +260,12 @@ def test_large_neighbourhoods_up_to_128(ctx, oracle):
     bad = np.abs(got.data_.T - ref).max(1) > 1e-9 * 100.0
     assert bad.sum() <= 3, "too many points differ: %d" % bad.sum()
     pn = geometry.PointCloud(pts)
-    pn.EstimateNormals(geometry.KDTreeSearchParamKNN(128), ctx=ctx)
-    assert _normals_close(pn.normals_, oracle.estimate_normals(pts, oracle.KNN, 128, 0.0)).mean() > 0.999
+    for k in (128, 256):
+        pn = geometry.PointCloud(pts)   # (a cloud that has normals gets the new ones oriented against them)
+        pn.EstimateNormals(geometry.KDTreeSearchParamKNN(k), ctx=ctx)
+        assert _normals_close(pn.normals_, oracle.estimate_normals(pts, oracle.KNN, k, 0.0)).mean() > 0.999
     with pytest.raises(_lib.O3DError):
-        pn.EstimateNormals(geometry.KDTreeSearchParamKNN(129), ctx=ctx)   # beyond the LDS lists: refused, not truncated
+        pn.EstimateNormals(geometry.KDTreeSearchParamKNN(257), ctx=ctx)   # beyond the LDS lists: refused, not truncated
 
 
 def test_fpfh_edge_cases(ctx):
