@@ -314,6 +314,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->sint_sorted) (void)hipFree(ctx->sint_sorted);
   for (hipEvent_t e : ctx->prof_ev)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->poll_ev) (void)hipEventDestroy(ctx->poll_ev);
   o3d_tmp_release_all(ctx);
   o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -439,6 +440,8 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   for (int i = 0; i < 16; i++) { hs->T[i] = init[i]; hs->update[i] = init[i]; }
   hs->rel_fitness = rel_fitness;
   hs->rel_rmse = rel_rmse;
+  ctx->rel_fitness = rel_fitness;
+  ctx->rel_rmse = rel_rmse;
   hs->n_src_global = (double)n_src_global;
   ctx->n_src_global = n_src_global;
   hs->max_iter = max_iter;
@@ -646,15 +649,27 @@ int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
 static int run_icp_loop(o3d_ctx *ctx, int max_iter) {
   const int kChunk = 6;
   O3D_TRY(o3d_icp_step(ctx));
+  // IcpState::done is set by the convergence test (:162-165: |d fitness| < relative_fitness AND |d rmse| < relative_rmse)
+  // or at max_iteration: with a threshold that no absolute value is below, there is nothing to look for before the end.
+  const bool can_break = ctx->rel_fitness > 0.0 && ctx->rel_rmse > 0.0;
+  if (can_break && !ctx->poll_ev) O3D_HIP(ctx, hipEventCreateWithFlags(&ctx->poll_ev, hipEventDisableTiming));
+  // The flag of a chunk is copied behind it and read only after the NEXT chunk has been enqueued: the device never waits
+  // for the host (a blocking look after every chunk drained the stream five times in a 30-iteration call).  Iterations
+  // enqueued past the break are no-ops on the device.
+  volatile int *flag = reinterpret_cast<volatile int *>((char *)ctx->pinned + 3072);
+  bool pending = false;
   int it = 0;
   while (it < max_iter) {
     const int upto = it + kChunk < max_iter ? it + kChunk : max_iter;
     for (; it < upto; it++) O3D_TRY(o3d_icp_step(ctx));
-    if (it < max_iter) {
-      int done = 0;
-      O3D_TRY(o3d_icp_poll(ctx, &done, nullptr));
-      if (done) break;
+    if (!can_break || it >= max_iter) continue;
+    if (pending) {
+      O3D_HIP(ctx, hipEventSynchronize(ctx->poll_ev));
+      if (*flag) break;
     }
+    O3D_HIP(ctx, hipMemcpyAsync((void *)flag, &ctx->state->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipEventRecord(ctx->poll_ev, ctx->stream));
+    pending = true;
   }
   return O3D_OK;
 }

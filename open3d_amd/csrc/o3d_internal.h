@@ -115,6 +115,8 @@ struct o3d_ctx {
   size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void *pinned = nullptr;  // 4 KiB pinned host staging
   void *xfer = nullptr;    // staged-copy state (xfer.hip), created by the first large host <-> device copy
+  hipEvent_t poll_ev = nullptr;  // run_icp_loop: the copy of IcpState::done behind a chunk of iterations
+  double rel_fitness = 0.0, rel_rmse = 0.0;  // the criteria of the last o3d_icp_setup
   // per-call device temporaries (copies of host inputs, staged outputs): blocks are kept between calls, see o3d_tmp_alloc
   struct TmpBlock { void *p; size_t cap; };
   std::vector<TmpBlock> tmp_idle, tmp_live;
