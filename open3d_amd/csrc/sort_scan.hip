@@ -74,7 +74,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
   __shared__ uint32_t dbase[256];         // first place of a digit in the tile's own sorted order
   __shared__ uint32_t wtot[kWaves];
   __shared__ KeyT skey[kSortTile];        // the tile in digit order: neighbouring lanes then write neighbouring words
-  __shared__ uint32_t sval[kSortTile];
+  __shared__ uint16_t sidx[kSortTile];    // where in the tile the key came from (its value is fetched from there)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < kWaves; w++) wcnt[w][threadIdx.x] = 0;
@@ -97,14 +97,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
 
   const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * (O3D_WAVE * kSortItems);
   KeyT k[kSortItems];
-  uint32_t rank[kSortItems], v[kSortItems];
+  uint32_t rank[kSortItems];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int it = 0; it < kSortItems; it++) {
     const int64_t i = wbase + it * O3D_WAVE + lane;
     const bool valid = i < n;
     k[it] = valid ? keys[i] : (KeyT)0;
-    v[it] = valid ? vals[i] : 0u;
     const uint32_t d = (uint32_t)(k[it] >> shift) & 255u;
     // lanes of this row holding the same digit (wave64 match-any by 8 ballots); invalid lanes match nobody
     uint64_t peers = __ballot(valid);
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
       const uint32_t d = (uint32_t)(k[it] >> shift) & 255u;
       const uint32_t lp = dbase[d] + wcnt[wave][d] + rank[it];
       skey[lp] = k[it];
-      sval[lp] = v[it];
+      sidx[lp] = (uint16_t)(wave * (O3D_WAVE * kSortItems) + it * O3D_WAVE + lane);
     }
   }
   __syncthreads();
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
       const uint32_t d = (uint32_t)(key >> shift) & 255u;
       const uint32_t pos = gbase[d] + (j - dbase[d]);
       out_keys[pos] = key;
-      out_vals[pos] = sval[j];
+      out_vals[pos] = vals[tile0 + sidx[j]];
     }
   }
 }
