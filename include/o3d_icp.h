@@ -142,6 +142,23 @@ O3D_API int o3d_registration_icp_batch(o3d_ctx *ctx, int64_t n_pairs, const doub
 O3D_API int o3d_compute_transformation(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz,
                                const double *tgt_nrm, int64_t n_tgt, const int32_t *corres_pairs, int64_t n_corres,
                                int estimation, int with_scaling, int mem, double out_transformation[16]);
+/* No counterpart in the reference.  o3d_compute_transformation (and, through out[16..17], o3d_compute_rmse) for callers that
+ * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No context: the
+ * kernels' scratch (one 32-double partial row per workgroup + the count of out-of-range pairs, 512.25 KiB) is a file-scope
+ * device array that every GPU the library runs on holds until the process ends.  The call allocates and frees nothing, does
+ * not synchronise, and only enqueues one memset and two kernels on `hip_stream` (a hipStream_t; NULL = the null stream) of
+ * device `device_id`.  Every buffer is DEVICE memory.  d_out20 receives 20 doubles: [0..15] the transformation
+ * (column-major), [16] point-to-point RMSE, [17] point-to-plane RMSE (0 without normals), [18] number of pairs used,
+ * [19] number of pairs with an index outside the clouds (the result is only valid when it is 0).  Sizes above
+ * O3D_NOALLOC_MAX_CORRES are rejected with O3D_ERR_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (different streams or threads) race; serialise them.  The array's address is looked up with
+ * hipGetSymbolAddress by o3d_ctx_create or, failing that, by the first call on the device -- make one of the two happen
+ * before a graph capture begins. */
+#define O3D_NOALLOC_MAX_CORRES 2147483647LL
+O3D_API int o3d_compute_transformation_noalloc(int device_id, void *hip_stream, const double *d_src_xyz, int64_t n_src,
+                                       const double *d_tgt_xyz, const double *d_tgt_nrm, int64_t n_tgt,
+                                       const int32_t *d_corres_pairs, int64_t n_corres, int estimation, int with_scaling,
+                                       double *d_out20);
 /* TransformationEstimationPointToPoint / PointToPlane::ComputeRMSE, TransformationEstimation.cpp:38-47,62-72. */
 O3D_API int o3d_compute_rmse(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
                      int64_t n_tgt, const int32_t *corres_pairs, int64_t n_corres, int estimation, int mem, double *out_rmse);
@@ -206,9 +223,14 @@ O3D_API int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_
 /* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 search kernel +
  * accumulation kernel instead of the default cooperative fp32-prefilter search (both give the exact result);
  * collect_tile_stats != 0 makes the cooperative search count {wave trips, dense item trips, runs listed, queries resolved
- * by the exact fp64 search, items, valid lanes} (process-wide counters, read by o3d_debug_tile_stats). */
+ * by the exact fp64 search, items, valid lanes, queries certified without a search} (per-context counters in device memory,
+ * read by o3d_debug_tile_stats). */
 O3D_API int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats);
 O3D_API int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset);
+/* Test hook, no reference counterpart: sets THIS context's count of fp32 winners whose fp64 confirmation failed, as the
+ * search kernel would; the next o3d_icp_finish / o3d_icp_fetch on this context (and on no other) then returns
+ * O3D_ERR_STATE.  The counter is cleared by o3d_icp_setup and by the call that reports it. */
+O3D_API int o3d_debug_inject_bound_violation(o3d_ctx *ctx, unsigned int count);
 /* Processing order of the source shard after o3d_icp_setup: out[p] = caller's index of the p-th processed point. */
 O3D_API int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out);
 /* Timing breakdown of the last setup (milliseconds, HIP events): [0] grid build, [1] source upload+sort. */

@@ -44,6 +44,8 @@ _SIGNATURES = {
                                              C.c_void_p]),
     "o3d_compute_transformation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_int64, C.c_int, C.c_int, C.c_int, c_dp]),
+    "o3d_compute_transformation_noalloc": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                                     C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "o3d_compute_rmse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.c_int, C.c_int, c_dp]),
     "o3d_information_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, c_dp, C.c_int,
@@ -58,6 +60,7 @@ _SIGNATURES = {
     "o3d_icp_pass_to": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_debug_set": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "o3d_debug_tile_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "o3d_debug_inject_bound_violation": (C.c_int, [C.c_void_p, C.c_uint]),
     "o3d_debug_get_source_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
@@ -199,7 +202,7 @@ class Context:
     def tile_stats(self, reset=True):
         out = (C.c_uint64 * 8)()
         self.check(self._lib.o3d_debug_tile_stats(self._h, out, int(reset)))
-        keys = ["wave_iters", "item_trips", "runs", "exact_lanes", "items", "valid_lanes", "_6", "_7"]
+        keys = ["wave_iters", "item_trips", "runs", "exact_lanes", "items", "valid_lanes", "certified", "_7"]
         return dict(zip(keys, [int(v) for v in out]))
 
     @property

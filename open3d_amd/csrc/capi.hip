@@ -20,12 +20,11 @@
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
-int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset);
-int o3d_take_bound_violations(o3d_ctx *ctx, unsigned int *out);
 int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
 int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
                      const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad);
 int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]);
+int o3d_noalloc_prepare_device(int device);
 int o3d_launch_set_hypothesis(o3d_ctx *ctx, const double T[16]);
 int o3d_launch_color_gather(o3d_ctx *ctx, const double *d_tgt_col, const double *d_grad, const double *d_src_col);
 int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double radius,
@@ -290,6 +289,10 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   if ((e = hipMalloc((void **)&ctx->state, sizeof(IcpState))) != hipSuccess) return bail(e, "hipMalloc state");
   if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
   if ((e = hipMalloc((void **)&ctx->sums, sizeof(double) * O3D_NSUMS)) != hipSuccess) return bail(e, "hipMalloc sums");
+  if ((e = hipMalloc((void **)&ctx->counters, sizeof(unsigned long long) * O3D_NCOUNTERS)) != hipSuccess) return bail(e, "hipMalloc counters");
+  if ((e = hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+  // the scratch address of o3d_compute_transformation_noalloc on this device, so that its first call may come under capture
+  if (o3d_noalloc_prepare_device(device_id) != O3D_OK) return bail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
   *out_ctx = ctx;
   return O3D_OK;
 }
@@ -302,7 +305,8 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log};
+                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
+                  ctx->counters};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -341,12 +345,22 @@ int o3d_ctx_use_own_stream(o3d_ctx *ctx) {
 }
 
 // The fp32 prefilter's error bound is checked on every winner (k_icp_search_coop); a violation makes the result suspect.
+// The counter lives in the context's own device memory and travels with the state copy of o3d_icp_finish / o3d_icp_fetch
+// (kViolationSlot of the pinned page): no symbol copy, no synchronisation beyond the one the caller makes anyway.
+static constexpr size_t kViolationSlot = 3584;  // byte offset in ctx->pinned
+static hipError_t enqueue_violation_read(o3d_ctx *ctx) {
+  return hipMemcpyAsync((char *)ctx->pinned + kViolationSlot, ctx->counters + O3D_CTR_VIOLATIONS, sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost, ctx->stream);
+}
+// after the stream has been synchronised
 static int check_bound_violations(o3d_ctx *ctx) {
-  unsigned int v = 0;
-  O3D_TRY(o3d_take_bound_violations(ctx, &v));
-  if (v)
-    return o3d_fail(ctx, O3D_ERR_STATE, "internal: %u fp32 prefilter winner(s) failed their fp64 confirmation; the result is not "
+  unsigned long long v = 0;
+  memcpy(&v, (char *)ctx->pinned + kViolationSlot, sizeof v);
+  if (v) {
+    O3D_HIP(ctx, hipMemsetAsync(ctx->counters + O3D_CTR_VIOLATIONS, 0, sizeof(unsigned long long), ctx->stream));
+    return o3d_fail(ctx, O3D_ERR_STATE, "internal: %llu fp32 prefilter winner(s) failed their fp64 confirmation; the result is not "
                     "trustworthy (o3d_debug_set(ctx, 1, 0) selects the all-fp64 path)", v);
+  }
   return O3D_OK;
 }
 
@@ -373,9 +387,17 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   DeviceGuard guard(ctx->device);
   o3d_staging *sg = staging_of(ctx);
 
-  hipEvent_t ev[3];
-  for (auto &e : ev) O3D_HIP(ctx, hipEventCreate(&e));
+  struct Events {  // destroyed on every return path
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    ~Events() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+    hipEvent_t &operator[](int i) { return e[i]; }
+  } ev;
+  for (auto &e : ev.e) O3D_HIP(ctx, hipEventCreate(&e));
   O3D_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream));
 
   const void *d_tgt, *d_nrm, *d_src;
   O3D_TRY(to_device(ctx, tgt_xyz, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[0], &sg->cap[0], &d_tgt));
@@ -457,7 +479,6 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   (void)hipEventElapsedTime(&ms1, ev[1], ev[2]);
   ctx->setup_ms[0] = ms0;
   ctx->setup_ms[1] = ms1;
-  for (auto &e : ev) (void)hipEventDestroy(e);
   ctx->enq_passes = 0;
   ctx->sums_valid = 0;
   ctx->hyp_mode = 0;
@@ -512,6 +533,17 @@ int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) 
   return O3D_OK;
 }
 
+int o3d_debug_inject_bound_violation(o3d_ctx *ctx, unsigned int count) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  unsigned long long *h = reinterpret_cast<unsigned long long *>((char *)ctx->pinned + kViolationSlot + 192);
+  *h = count;
+  O3D_HIP(ctx, hipMemcpyAsync(ctx->counters + O3D_CTR_VIOLATIONS, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
 int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
   if (!ctx || !host_out) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);
@@ -526,8 +558,10 @@ int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
   if (!ctx || !out) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);
   DeviceGuard guard(ctx->device);
-  unsigned long long t[8];
-  O3D_TRY(o3d_read_tile_stats(ctx, t, reset));
+  unsigned long long *t = reinterpret_cast<unsigned long long *>((char *)ctx->pinned + kViolationSlot + 64);
+  O3D_HIP(ctx, hipMemcpyAsync(t, ctx->counters, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (reset) O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * 8, ctx->stream));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 8; i++) out[i] = t[i];
   return O3D_OK;
 }
@@ -609,6 +643,7 @@ int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, i
   }
   IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
   O3D_HIP(ctx, o3d_d2h(ctx, hs, ctx->state, sizeof(IcpState)));
+  O3D_HIP(ctx, enqueue_violation_read(ctx));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   O3D_TRY(check_bound_violations(ctx));
   if (out_T) memcpy(out_T, hs->T, sizeof(double) * 16);
@@ -648,6 +683,7 @@ int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
 // (IcpState::done).  The host looks at the flag every kChunk iterations to stop enqueueing early.
 static int run_icp_loop(o3d_ctx *ctx, int max_iter) {
   const int kChunk = 6;
+  DeviceGuard guard(ctx->device);  // the event and the copy below belong to the context's device, whatever the caller's is
   O3D_TRY(o3d_icp_step(ctx));
   // IcpState::done is set by the convergence test (:162-165: |d fitness| < relative_fitness AND |d rmse| < relative_rmse)
   // or at max_iteration: with a threshold that no absolute value is below, there is nothing to look for before the end.
@@ -680,6 +716,7 @@ int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, con
                          int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);  // held for the whole call
+  DeviceGuard guard(ctx->device);
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
                         rel_rmse, max_iter, mem, n_src));
   O3D_TRY(run_icp_loop(ctx, max_iter));
@@ -693,6 +730,7 @@ int o3d_registration_colored_icp(o3d_ctx *ctx, const double *src_xyz, const doub
                                  double *out_gradients) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);  // held for the whole call
+  DeviceGuard guard(ctx->device);
   if (!src_col || !tgt_col) {
     // ColoredICP.cpp:127-128: without colours every update is the identity; the loop of Registration.cpp:154-166 then
     // stops after its first iteration with the result of the initial search (and zero gradients where they exist)
@@ -830,6 +868,7 @@ int o3d_icp_fetch(o3d_ctx *ctx, int mem, int32_t *out_corr, int64_t *out_n_corr,
   }
   double *hq = reinterpret_cast<double *>(ctx->pinned);
   O3D_HIP(ctx, o3d_d2h(ctx, hq, ctx->sums, sizeof(double) * O3D_NSUMS));
+  O3D_HIP(ctx, enqueue_violation_read(ctx));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   O3D_TRY(check_bound_violations(ctx));
   const double nc = hq[O3D_SUM_NC];

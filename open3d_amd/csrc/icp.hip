@@ -17,6 +17,8 @@
 // file is compiled with -ffp-contract=off), accept iff d2 < (double)(float)(r*r), argmin over (d2, target index).
 #include <math.h>
 
+#include <mutex>
+
 #include "o3d_internal.h"
 
 namespace {
@@ -261,14 +263,16 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
   }
 }
 
-// Optional counters of the cooperative search (tests and tuning): [0] wave trips, [1] dense item trips, [2] runs
-// listed, [3] queries resolved by the exact fp64 search, [4] items (four candidates each), [5] valid lanes.
-__device__ unsigned long long g_tile_stats[8];
-// number of fp32 winners whose fp64 confirmation failed (must stay 0: see k_icp_search_coop)
-__device__ unsigned int g_bound_violations;
+// Per-context counters in device memory (o3d_ctx::counters, PassArgs::ctr): contexts that run concurrently on one GPU
+// (batch workers, shards rehearsed on one device) never see each other's.
+//   [0..7] optional statistics of the cooperative search (tests and tuning): [0] wave trips, [1] dense item trips, [2] runs
+//          listed, [3] queries resolved by the exact fp64 search, [4] items (four candidates each), [5] valid lanes,
+//          [6] queries whose previous match was certified without a search
+//   [8]    number of fp32 winners whose fp64 confirmation failed (must stay 0: see k_icp_search_coop)
 
 struct PassArgs {
   int stats;
+  unsigned long long *ctr;  // the context's counters (O3D_CTR_*)
   double *src;           // source in processing order: transformed in place (written by the search kernels)
   const double *src_in;  // where the search kernels read the source from: src, or the untouched copy (hypothesis mode)
   int64_t n_src;
@@ -579,7 +583,8 @@ __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_
 // which the atomics land.  What is not decisive in fp32 is searched again exactly in fp64 on the spot.
 constexpr int kQCap = 256;            // items per wavefront and round (mean demand is ~260; more rounds when it overflows)
 constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
-constexpr uint32_t kRunMaxLen = 1u << 28;
+// an item carries 22 bits of four-candidate chunk index: longer runs go to the exact wave search
+constexpr uint32_t kRunMaxLen = 1u << 24;
 struct CoopWave {
   union {
     uint2 runs[kMaxRuns][O3D_WAVE];   // [slot][lane]: the lane's run list (phase 1: slot 0 = centre cell)
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     // resolved exactly before they got here).  It is counted; o3d_icp_finish / o3d_icp_fetch then fail loudly instead of
     // returning a result that might not be exact.
     if (use_p && !(d2 < a.thr)) {
-      atomicAdd(&g_bound_violations, 1u);
+      atomicAdd(&a.ctr[O3D_CTR_VIOLATIONS], 1ull);
       use_p = false;
     }
     if (had_p) a.corr[i_p] = use_p ? (int32_t)__double_as_longlong(p_p.w) : O3D_CORR_NONE;
@@ -891,12 +896,12 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
         isum += __shfl_xor(isum, d, O3D_WAVE);
       }
       if (lane == 0) {
-        atomicAdd(&g_tile_stats[0], 1ull);
-        atomicAdd(&g_tile_stats[1], (unsigned long long)trips);
-        atomicAdd(&g_tile_stats[2], rsum);
-        atomicAdd(&g_tile_stats[3], np);
-        atomicAdd(&g_tile_stats[4], isum);
-        atomicAdd(&g_tile_stats[5], nv);
+        atomicAdd(&a.ctr[0], 1ull);
+        atomicAdd(&a.ctr[1], (unsigned long long)trips);
+        atomicAdd(&a.ctr[2], rsum);
+        atomicAdd(&a.ctr[3], np);
+        atomicAdd(&a.ctr[4], isum);
+        atomicAdd(&a.ctr[5], nv);
       }
     }
     if (valid) {
@@ -1405,7 +1410,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_pairs_accumulate(PairArgs a) {
 // out[0..15] = ComputeTransformation (column-major), out[16] = point-to-point RMSE, out[17] = point-to-plane RMSE,
 // out[18] = number of pairs used.
 __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, int nparts, int estimation, int with_scaling,
-                                                                     double *__restrict__ out) {
+                                                                     double *__restrict__ out, int write_bad) {
   __shared__ double s[32][O3D_NSUMS];
   finalize_sums(a.partials, nparts, s);
   if (threadIdx.x != 0) return;
@@ -1435,6 +1440,7 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_pairs_estimate(PairArgs a, 
   out[16] = nc > 0.0 ? sqrt(q[O3D_SUM_D2] / nc) : 0.0;
   out[17] = (nc > 0.0 && a.nrm) ? sqrt(q[27] / nc) : 0.0;
   out[18] = nc;
+  if (write_bad) out[19] = (double)*a.bad;  // o3d_compute_transformation_noalloc: the caller has no other way to see it
 }
 
 // RegistrationRANSACBasedOnFeatureMatching, Registration.cpp:250-268, one lane per candidate correspondence set: the
@@ -1589,23 +1595,101 @@ int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out) {
   return O3D_OK;
 }
 
-// dev_out: 19 doubles (see k_pairs_estimate); dev_bad: one int, zeroed here.
-int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
-                     const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad) {
+// dev_out: 19 doubles (see k_pairs_estimate), 20 with write_bad; dev_bad: one int, zeroed here.  Allocates nothing.
+static hipError_t launch_pairs_on(hipStream_t stream, double *partials, const double *d_src, int64_t n_src, const double *d_tgt,
+                                  const double *d_nrm, int64_t n_tgt, const int32_t *d_pairs, int64_t n_pairs, int estimation,
+                                  int with_scaling, double *dev_out, int *dev_bad, int write_bad) {
   PairArgs a;
   a.src = d_src; a.n_src = n_src; a.tgt = d_tgt; a.nrm = d_nrm; a.n_tgt = n_tgt; a.pairs = d_pairs; a.n_pairs = n_pairs;
-  a.partials = ctx->partials; a.bad = dev_bad;
+  a.partials = partials; a.bad = dev_bad;
   int64_t g = (n_pairs + O3D_BLOCK - 1) / O3D_BLOCK;
   if (g < 1) g = 1;
   if (g > O3D_MAX_GRID) g = O3D_MAX_GRID;
-  O3D_HIP(ctx, hipMemsetAsync(dev_bad, 0, sizeof(int), ctx->stream));
+  hipError_t e = hipMemsetAsync(dev_bad, 0, sizeof(int), stream);
+  if (e != hipSuccess) return e;
   if (estimation == O3D_EST_POINT_TO_PLANE && d_nrm)
-    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_PLANE>, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_PLANE>, dim3((int)g), dim3(O3D_BLOCK), 0, stream, a);
   else
-    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_POINT>, dim3((int)g), dim3(O3D_BLOCK), 0, ctx->stream, a);
-  hipLaunchKernelGGL(k_pairs_estimate, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, a, (int)g, estimation, with_scaling, dev_out);
-  O3D_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_pairs_accumulate<O3D_EST_POINT_TO_POINT>, dim3((int)g), dim3(O3D_BLOCK), 0, stream, a);
+  hipLaunchKernelGGL(k_pairs_estimate, dim3(1), dim3(O3D_FIN_THREADS), 0, stream, a, (int)g, estimation, with_scaling, dev_out,
+                     write_bad);
+  return hipGetLastError();
+}
+
+int o3d_launch_pairs(o3d_ctx *ctx, const double *d_src, int64_t n_src, const double *d_tgt, const double *d_nrm, int64_t n_tgt,
+                     const int32_t *d_pairs, int64_t n_pairs, int estimation, int with_scaling, double *dev_out, int *dev_bad) {
+  O3D_HIP(ctx, launch_pairs_on(ctx->stream, ctx->partials, d_src, n_src, d_tgt, d_nrm, n_tgt, d_pairs, n_pairs, estimation,
+                               with_scaling, dev_out, dev_bad, 0));
   return O3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// o3d_compute_transformation_noalloc: the same two kernels for callers that cannot allocate (code under HIP graph capture,
+// serving loops, harnesses that forbid hipMalloc).  Their scratch -- one 32-double partial row per workgroup and the count
+// of out-of-range pairs -- lives in this file-scope device array instead of a context's buffers.  Every GPU the library
+// runs on holds its own copy (512.25 KiB) at its own address until the process ends; the address is looked up once per
+// device with hipGetSymbolAddress and host code only ever uses that pointer, never the array's name.
+constexpr size_t kNoAllocPartialBytes = sizeof(double) * O3D_NSUMS * O3D_MAX_GRID;
+constexpr size_t kNoAllocBytes = kNoAllocPartialBytes + 256;
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+constexpr int kNoAllocMaxDevices = 64;
+static std::mutex g_noalloc_mu;
+static void *g_noalloc_ptr[kNoAllocMaxDevices] = {};
+
+// `device` must be the current device.  Returns the device's scratch address, or nullptr with *err set.
+static void *noalloc_scratch_of(int device, hipError_t *err) {
+  *err = hipSuccess;
+  if (device < 0 || device >= kNoAllocMaxDevices) { *err = hipErrorInvalidDevice; return nullptr; }
+  std::lock_guard<std::mutex> lk(g_noalloc_mu);
+  if (!g_noalloc_ptr[device]) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) { *err = e != hipSuccess ? e : hipErrorInvalidSymbol; return nullptr; }
+    g_noalloc_ptr[device] = p;
+  }
+  return g_noalloc_ptr[device];
+}
+
+// Called by o3d_ctx_create with the context's device current, so that a later call under graph capture finds the
+// address already there.
+int o3d_noalloc_prepare_device(int device) {
+  hipError_t e;
+  return noalloc_scratch_of(device, &e) ? O3D_OK : O3D_ERR_HIP;
+}
+
+extern "C" int o3d_compute_transformation_noalloc(int device_id, void *hip_stream, const double *d_src_xyz, int64_t n_src,
+                                                  const double *d_tgt_xyz, const double *d_tgt_nrm, int64_t n_tgt,
+                                                  const int32_t *d_corres_pairs, int64_t n_corres, int estimation, int with_scaling,
+                                                  double *d_out20) {
+  if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
+    return o3d_fail(nullptr, O3D_ERR_UNSUPPORTED, "o3d_compute_transformation_noalloc: estimation type %d is not on the device path", estimation);
+  if (!d_out20 || n_src < 0 || n_tgt < 0 || n_corres < 0 || (n_corres > 0 && (!d_corres_pairs || !d_src_xyz || !d_tgt_xyz)))
+    return o3d_fail(nullptr, O3D_ERR_INVALID_ARG, "o3d_compute_transformation_noalloc: bad sizes or null buffers");
+  if (n_corres > O3D_NOALLOC_MAX_CORRES || n_src > O3D_NOALLOC_MAX_CORRES || n_tgt > O3D_NOALLOC_MAX_CORRES)
+    return o3d_fail(nullptr, O3D_ERR_UNSUPPORTED, "o3d_compute_transformation_noalloc: %lld correspondences over %lld x %lld points "
+                    "exceed the entry point's maximum of %lld each", (long long)n_corres, (long long)n_src, (long long)n_tgt,
+                    (long long)O3D_NOALLOC_MAX_CORRES);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+    return o3d_fail(nullptr, O3D_ERR_HIP, "o3d_compute_transformation_noalloc: no HIP device %d (libo3d_amd has no CPU fallback)", device_id);
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  if (prev != device_id && hipSetDevice(device_id) != hipSuccess)
+    return o3d_fail(nullptr, O3D_ERR_HIP, "o3d_compute_transformation_noalloc: hipSetDevice(%d) failed", device_id);
+  hipError_t e;
+  unsigned char *sp = static_cast<unsigned char *>(noalloc_scratch_of(device_id, &e));
+  int st = O3D_OK;
+  if (!sp) {
+    st = o3d_fail(nullptr, O3D_ERR_HIP, "o3d_compute_transformation_noalloc: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+  } else {
+    // the array keeps the previous call's contents: the bad-pair count is cleared on the stream, every partial row the
+    // estimate reads is written by this call's accumulation first
+    e = launch_pairs_on((hipStream_t)hip_stream, reinterpret_cast<double *>(sp), d_src_xyz, n_src, d_tgt_xyz, d_tgt_nrm, n_tgt,
+                        d_corres_pairs, n_corres, estimation, with_scaling, d_out20, reinterpret_cast<int *>(sp + kNoAllocPartialBytes), 1);
+    if (e != hipSuccess) st = o3d_fail(nullptr, O3D_ERR_HIP, "o3d_compute_transformation_noalloc: launch: %s", hipGetErrorString(e));
+  }
+  if (prev >= 0 && prev != device_id) (void)hipSetDevice(prev);
+  return st;
 }
 
 int o3d_launch_ransac_hypotheses(o3d_ctx *ctx, const RansacArgs &a) {
@@ -1632,6 +1716,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   }
   PassArgs pa;
   pa.stats = ctx->tile_stats;
+  pa.ctr = ctx->counters;
   pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
@@ -1713,23 +1798,3 @@ int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out) {
   return O3D_OK;
 }
 
-// Reads and clears the counter of failed confirmations (synchronises the stream).
-int o3d_take_bound_violations(o3d_ctx *ctx, unsigned int *out) {
-  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  O3D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bound_violations), sizeof(unsigned int)));
-  if (*out) {
-    const unsigned int z = 0;
-    O3D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bound_violations), &z, sizeof z));
-  }
-  return O3D_OK;
-}
-
-int o3d_read_tile_stats(o3d_ctx *ctx, unsigned long long out[8], int reset) {
-  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  O3D_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 8));
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    O3D_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), z, sizeof z));
-  }
-  return O3D_OK;
-}

@@ -22,6 +22,11 @@
 #define O3D_SUM_D2 28
 #define O3D_SUM_NC 29
 
+// per-context device counters (o3d_ctx::counters): [0..7] search statistics, [8] failed fp64 confirmations
+#define O3D_NCOUNTERS 16
+#define O3D_CTR_CERTIFIED 6
+#define O3D_CTR_VIOLATIONS 8
+
 struct GridParams {
   double gmin[3];  // grid origin (min of the finite target points minus the margin of empty cells)
   double inv_h;    // 1 / cell size
@@ -90,6 +95,7 @@ struct o3d_ctx {
 
   // loop
   IcpState *state = nullptr;   // device
+  unsigned long long *counters = nullptr;  // device, O3D_NCOUNTERS entries, cleared by o3d_icp_setup
   double *partials = nullptr;  // [grid][32]
   double *sums = nullptr;      // [32] local
   double *log = nullptr;       // [(max_iter+1)][O3D_LOG_STRIDE]

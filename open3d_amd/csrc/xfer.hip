@@ -93,7 +93,11 @@ hipError_t xfer_init(o3d_ctx *ctx) {
   }
   ctx->xfer = x;  // o3d_xfer_destroy releases whatever was created
   x->device = ctx->device;
-  if (e == hipSuccess) {
+  if (e != hipSuccess) {  // half-built state must not be taken for a working one by the next copy
+    o3d_xfer_destroy(ctx);
+    return e;
+  }
+  {
     try {
       for (int t = 1; t < kThreads; t++) x->th[t] = std::thread(xfer_worker, x, t);
     } catch (...) {  // no thread to be had: the copy falls back to the runtime's path (see staged_copy)

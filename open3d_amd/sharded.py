@@ -28,11 +28,25 @@ class HipEngine:
     def __init__(self, ctx=None):
         from .pipelines.registration import IcpSession
         self.sess = IcpSession(ctx)
+        self._bound = None
+
+    def bind_stream(self):
+        """The pass and solve kernels, and the collective torch.distributed issues between them, must be ordered: put
+        the context on torch's current stream (re-bound whenever that stream has changed since the last call)."""
+        import torch
+        ctx = self.sess.ctx
+        with torch.cuda.device(ctx.device):
+            h = int(torch.cuda.current_stream().cuda_stream)
+        if self._bound != h:
+            ctx.set_stream(h)
+            self._bound = h
 
     def setup(self, src, tgt, tgt_normals, max_dist, init, estimation, criteria, n_src_global):
+        self.bind_stream()
         self.sess.setup(src, tgt, tgt_normals, max_dist, init, estimation, criteria, n_src_global)
 
     def pass_into(self, local_sums):
+        self.bind_stream()
         self.sess.enqueue_pass_to(local_sums.data_ptr())
 
     def solve_from(self, all_sums, n_ranks):
