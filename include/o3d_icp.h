@@ -220,6 +220,8 @@ O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_cou
 /* Same, split: out_mean_ms[0] = k_icp_search_coop (the one kernel of a pass; k_icp_search on the alternative path),
  * [1] = k_icp_accumulate_mfma (alternative path only; otherwise ~0). */
 O3D_API int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count);
+/* Same record, pass by pass (search + accumulation kernels of each recorded pass, milliseconds); does not clear it. */
+O3D_API int o3d_icp_profile_read_all(o3d_ctx *ctx, double *out_ms, int max_count, int *out_count);
 /* Test / tuning hooks (no reference counterpart).  force_generic_pass != 0 selects the per-lane fp64 search kernel +
  * accumulation kernel instead of the default cooperative fp32-prefilter search (both give the exact result);
  * collect_tile_stats != 0 makes the cooperative search count {wave trips, dense item trips, runs listed, queries resolved

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
     "o3d_icp_profile_read2": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
+    "o3d_icp_profile_read_all": (C.c_int, [C.c_void_p, c_dp, C.c_int, C.POINTER(C.c_int)]),
     "o3d_icp_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "o3d_icp_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "o3d_icp_finish": (C.c_int, [C.c_void_p, C.c_int, c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp,

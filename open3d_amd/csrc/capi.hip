@@ -305,7 +305,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->pos_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
+                  ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
                   ctx->counters};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -450,6 +450,11 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   }
   ctx->search_grid = (int)gs;
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
+  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : 1;  // tuning aid
+  if (const char *e = getenv("O3D_CERT_GAP")) {
+    const double v = atof(e);
+    if (v >= 0.0 && v <= 1.0) ctx->cert_gap = v;
+  }
   const int rows = max_iter + 1;
   if (rows > ctx->log_rows || !ctx->log) {
     if (ctx->log) (void)hipFree(ctx->log);
@@ -601,6 +606,21 @@ int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count) {
   }
   if (out_count) *out_count = ctx->prof_n;
   ctx->prof_n = 0;
+  return O3D_OK;
+}
+
+int o3d_icp_profile_read_all(o3d_ctx *ctx, double *out_ms, int max_count, int *out_count) {
+  if (!ctx || !out_ms || max_count < 0) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = ctx->prof_n < max_count ? ctx->prof_n : max_count;
+  for (int i = 0; i < n; i++) {
+    float ms = 0;
+    O3D_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[3 * i], ctx->prof_ev[3 * i + 2]));
+    out_ms[i] = ms;
+  }
+  if (out_count) *out_count = n;
   return O3D_OK;
 }
 

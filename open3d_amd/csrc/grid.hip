@@ -443,7 +443,9 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     if (ctx->corr_sorted) (void)hipFree(ctx->corr_sorted);
     if (ctx->corr_out) (void)hipFree(ctx->corr_out);
     if (ctx->pos_sorted) (void)hipFree(ctx->pos_sorted);
+    if (ctx->lb_sorted) (void)hipFree(ctx->lb_sorted);
     ctx->pos_sorted = nullptr;
+    ctx->lb_sorted = nullptr;
     ctx->src_sorted = nullptr; ctx->src_perm = nullptr; ctx->corr_sorted = nullptr; ctx->corr_out = nullptr;
     ctx->cap_src = 0;
     O3D_HIP(ctx, hipMalloc((void **)&ctx->src_sorted, sizeof(double) * 3 * nn));
@@ -451,10 +453,12 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_sorted, sizeof(int32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_out, sizeof(int32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->pos_sorted, sizeof(uint32_t) * nn));
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->lb_sorted, sizeof(float) * nn));
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;
   O3D_HIP(ctx, hipMemsetAsync(ctx->pos_sorted, 0xFF, sizeof(uint32_t) * (size_t)n, ctx->stream));  // no previous match
+  O3D_HIP(ctx, hipMemsetAsync(ctx->lb_sorted, 0, sizeof(float) * (size_t)n, ctx->stream));          // ... and no bound
   const size_t ntiles = o3d_sort_num_tiles(n);
   const size_t nh = 256 * ntiles;
   void *keys, *tkeys, *tvals, *hist, *dT;

@@ -284,6 +284,9 @@ struct PassArgs {
   int32_t *corr;   // per processing position: target index, or -1 none
   uint32_t *pos;   // per processing position: position of the match in tgt_sorted (O3D_POS_NONE: none)
   int seed;        // k_icp_search_coop: use the previous pass's match as the first pruning bound
+  int cert;        // k_icp_search_coop: skip the search of a query whose previous match is certified to be its nearest still
+  float gap;       // ... and scan this far beyond the best distance, so that the bounds have slack (absolute length)
+  float *lb;       // per processing position: lower bound on the distance to every target point but the match
   double *partials;
   double thr;
   // coloured ICP only (ColoredICP.cpp:125-177)
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams
     nn_search(a.tgt, a.cell_start, gp, x, y, z, b);
     a.corr[i] = (int32_t)b.idx;
     a.pos[i] = b.idx >= 0 ? b.pos : O3D_POS_NONE;
+    a.lb[i] = 0.f;  // this search leaves no bound behind: a cooperative pass that follows searches everything
   }
 }
 
@@ -729,7 +733,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   // matched target point and normal
   // are issued at the end of a trip and consumed in the next one, behind that trip's own source loads, so that their
   // latency is not exposed.
-  bool use_p = false;  // carried from the previous trip
+  bool use_p = false;   // carried from the previous trip
+  bool cert_p = false;  // ... its candidate is a certified previous match (may lie beyond the radius: not a violation)
   int64_t i_p = 0;
   double4 p_p = make_double4(0.0, 0.0, 0.0, 0.0), tc_p = make_double4(0.0, 0.0, 0.0, 0.0);
   double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0, is_p = 0.0;
@@ -744,9 +749,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     }
     // A confirmation that fails would mean that the fp32 error bound does not hold (winners near the threshold were
     // resolved exactly before they got here).  It is counted; o3d_icp_finish / o3d_icp_fetch then fail loudly instead of
-    // returning a result that might not be exact.
+    // returning a result that might not be exact.  (A certified previous match is the nearest point whatever its
+    // distance: beyond the radius it simply is no correspondence, Registration.cpp:64-66.)
     if (use_p && !(d2 < a.thr)) {
-      atomicAdd(&a.ctr[O3D_CTR_VIOLATIONS], 1ull);
+      if (!cert_p) atomicAdd(&a.ctr[O3D_CTR_VIOLATIONS], 1ull);
       use_p = false;
     }
     if (had_p) a.corr[i_p] = use_p ? (int32_t)__double_as_longlong(p_p.w) : O3D_CORR_NONE;
@@ -754,133 +760,213 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     push_sums<EST>(wl.vb, lane, S, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0, tc_p, is_p, a.slg, a.slp);
   };
 
+  // Certificates (a.cert).  Next to its match m every query keeps lb, a lower bound on its distance to every target point
+  // OTHER than m (to every target point when it has no match), valid at the position the bound was last written for.  A
+  // pass moves the query by |dq|, so lb - |dq| bounds the same distances at the new position; while the new distance to
+  // m stays below that, m is still the unique nearest point and the search is skipped altogether -- the exact fp64
+  // distance to m, the radius test and the sums are computed as always.  Near convergence this is nearly every query.
+  // lb comes out of a search for free: the runner-up of the scanned candidates and the pruning reach (every cell the walk
+  // left out is farther than that), which a.gap widens beyond the winner's distance so that a bound has room to shrink.
+  // All bounds are fp32 rounded towards "certificate fails" with relative slack 1e-6, nine orders of magnitude above the
+  // rounding of the fp64 distances they stand for; equal distances (ties) can therefore never be certified.
+  const float cap = hf * (1.0f - 1e-6f);  // every point outside the 3x3x3 block, or around a query outside the grid interior
+  const float capsq = cap * cap;
+
+  struct Loc {
+    int cx, cy, cz;
+    bool inside;
+    float qx, qy, qz;
+    uint32_t s0, s1, s2, s3;
+    const uint32_t *rowp;
+  };
+  auto locate = [&](bool valid, double x, double y, double z) {
+    Loc L;
+    L.cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
+    L.cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
+    L.cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
+    L.inside = valid && L.cx >= 0 && L.cx < gp.nx && L.cy >= 1 && L.cy < gp.ny - 1 && L.cz >= 1 && L.cz < gp.nz - 1;
+    L.qx = L.qy = L.qz = 0.f;
+    L.s0 = L.s1 = L.s2 = L.s3 = 0;
+    L.rowp = cs;
+    if (L.inside) {
+      L.qx = (float)((x - gp.gmin[0]) - (double)L.cx * gp.h);
+      L.qy = (float)((y - gp.gmin[1]) - (double)L.cy * gp.h);
+      L.qz = (float)((z - gp.gmin[2]) - (double)L.cz * gp.h);
+      L.rowp = cs + (((uint32_t)L.cz * (uint32_t)gp.ny + (uint32_t)L.cy) * (uint32_t)gp.nxp + (uint32_t)L.cx);
+      const CellQuad qc = *reinterpret_cast<const CellQuad *>(L.rowp);
+      L.s0 = qc.v[0]; L.s1 = qc.v[1]; L.s2 = qc.v[2]; L.s3 = qc.v[3];
+    }
+    return L;
+  };
+
   for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
     const int64_t i = base + tid;
     const bool valid = i < end;
     double x = 0, y = 0, z = 0;
     uint32_t pprev = O3D_POS_NONE;
+    float lbv = 0.f, moved = 0.f;
     if (valid) {
       x = a.src_in[3 * i]; y = a.src_in[3 * i + 1]; z = a.src_in[3 * i + 2];
-      if (a.seed) pprev = a.pos[i];
+      if (a.seed || a.cert) pprev = a.pos[i];
+      if (a.cert) lbv = a.lb[i];
     }
     if (valid && apply) {
+      const double xo = x, yo = y, zo = z;
       apply_update(T, w, x, y, z);
       a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
+      const double mx = x - xo, my = y - yo, mz = z - zo;
+      moved = sqrtf((float)(mx * mx + my * my + mz * mz)) * (1.0f + 1e-6f);  // NaN for a non-finite point: never certified
     }
-    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
-    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
-    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
-    const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 1 && cy < gp.ny - 1 && cz >= 1 && cz < gp.nz - 1;
-    int32_t verdict = O3D_CORR_NONE;
-    float qx = 0, qy = 0, qz = 0;
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    const uint32_t *rowp = cs;
-    if (inside) {
-      qx = (float)((x - gp.gmin[0]) - (double)cx * gp.h);
-      qy = (float)((y - gp.gmin[1]) - (double)cy * gp.h);
-      qz = (float)((z - gp.gmin[2]) - (double)cz * gp.h);
-      rowp = cs + (((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx);
-      const CellQuad qc = *reinterpret_cast<const CellQuad *>(rowp);
-      s0 = qc.v[0]; s1 = qc.v[1]; s2 = qc.v[2]; s3 = qc.v[3];
-    }
-    // Seed: the target point this query matched in the previous pass.  Any target point bounds the nearest-neighbour
-    // distance from above; near convergence the previous match is (nearly) the nearest, so its exact distance prunes
-    // the block from the start and the centre-cell phase is skipped.  Only a bound: every cell it leaves is scanned and
-    // the winner comes out of the scan as always.
-    const bool has_seed = inside && pprev != O3D_POS_NONE;
+    // what the stored bound is still worth at the new position (<= 0, or NaN: worth nothing)
+    const float lbc = lbv * (1.0f - 1e-6f) - moved;
+    const bool has_prev = valid && pprev != O3D_POS_NONE;
+    // The target point this query matched in the previous pass: the certificate's point, and otherwise the seed.  Any
+    // target point bounds the nearest-neighbour distance from above; near convergence the previous match is (nearly) the
+    // nearest, so its exact distance prunes the block from the start and the centre-cell phase is skipped.  As a seed it
+    // is only a bound: every cell it leaves is scanned and the winner comes out of the scan as always.
     double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (has_seed) ps = a.tgt[pprev];
+    if (has_prev) ps = a.tgt[pprev];
+    // When every lane still holds a positive bound the wavefront will most likely skip the search: the cell table is then
+    // not touched up front (and, in the rare case that a certificate fails after all, loaded one latency later).
+    const bool optimistic = a.cert && __ballot(valid && !(lbc > 0.f)) == 0ull;
+    Loc L;
+    if (!optimistic) L = locate(valid, x, y, z);
     if (base != beg) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
-    bool too_long = s3 - s0 >= kRunMaxLen;
-    float seedb = INFINITY;
-    if (has_seed) {
+    double d2m = 0.0;
+    if (has_prev) {
       const double ddx = x - ps.x, ddy = y - ps.y, ddz = z - ps.z;
-      seedb = (float)(ddx * ddx + ddy * ddy + ddz * ddz) * 1.000001f + err;  // >= the exact distance, in fp32
+      d2m = ddx * ddx + ddy * ddy + ddz * ddz;
     }
-    const bool seeded = seedb <= seed_max && !too_long;
-    // phase 1: the centre cells of the wavefront's queries that have no usable seed
-    wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(cx + 1));
-    wl.best[lane] = kBestInit;
-    wl.second[lane] = 0x7F800000u;
-    wl.runs[kCentreSlot][lane] = make_run(s1, (too_long || seeded) ? s1 : s2, 0, 0);
-    wave_lds_sync();
-    unsigned trips = coop_phase(wl, lane, kCentreSlot, (too_long || seeded) ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
-    const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
-    // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
-    // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
-    // together), instead of eight loads per query up front.
+    bool certified = false;
+    if (a.cert && valid && lbc > 0.f) {
+      const float lb2 = lbc * lbc * (1.0f - 1e-6f);
+      certified = has_prev ? (float)d2m * (1.0f + 1e-6f) < lb2   // m is strictly nearer than everything else
+                           : lb2 > thrf * (1.0f + 1e-6f);         // nothing within the radius
+    }
+    int32_t verdict = O3D_CORR_NONE;
+    uint32_t bpos = O3D_POS_NONE;
+    float lbn = certified ? lbc : 0.f;  // the bound written for the next pass
+    unsigned trips = 0;
     int nruns = 0;
-    uint32_t tot = 0;
-    if (inside && !too_long) {
-      float t;
-      t = fmaxf(qx - margin, 0.f); const float axm = t * t;
-      t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
-      t = fmaxf(qy - margin, 0.f); const float aym = t * t;
-      t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
-      t = fmaxf(qz - margin, 0.f); const float azm = t * t;
-      t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
-      const float reach = fminf(best1, thrf + err) + 4.0f * err;
-      CellQuad rowq[9];
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        rowq[r].v[0] = rowq[r].v[1] = rowq[r].v[2] = rowq[r].v[3] = 0;
-        if (r == 4) continue;
-        const int dy = r % 3 - 1, dz = r / 3 - 1;
-        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
-        if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
+    uint32_t tot = 0, centre_items = 0;
+    unsigned long long undecided = 0ull;
+    if (certified && has_prev) {
+      // the previous trip's candidate has been consumed: its registers take this one right away, and the gathers of a
+      // certified match run behind whatever the rest of the wavefront still has to search
+      verdict = O3D_CORR_CANDIDATE;
+      bpos = pprev;
+      p_p = ps;
+      if (EST != O3D_EST_POINT_TO_POINT) {
+        n0_p = a.nrm[3 * (size_t)pprev]; n1_p = a.nrm[3 * (size_t)pprev + 1]; n2_p = a.nrm[3 * (size_t)pprev + 2];
       }
-      if (seeded) {  // centre row in one run: centre cell, and the left / right cell where the bound reaches them
-        const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
-        if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
-      } else {
-        if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
-        if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
-      }
+      if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[pprev]; is_p = a.sint[i]; }
+    }
+    if (__ballot(valid && !certified) != 0ull) {  // wave-uniform: somebody has to search
+      if (optimistic) L = locate(valid, x, y, z);
+      const bool act = L.inside && !certified;
+      if (valid && !certified && !L.inside) lbn = cap;  // at least one cell from every target point
+      const uint32_t s0 = L.s0, s1 = L.s1, s2 = L.s2, s3 = L.s3;
+      const float qx = L.qx, qy = L.qy, qz = L.qz;
+      const uint32_t *rowp = L.rowp;
+      bool too_long = s3 - s0 >= kRunMaxLen;
+      float seedb = INFINITY;
+      if (a.seed && act && has_prev) seedb = (float)d2m * 1.000001f + err;  // >= the exact distance, in fp32
+      const bool seeded = seedb <= seed_max && !too_long;
+      // phase 1: the centre cells of the wavefront's queries that have no usable seed
+      const bool skip1 = too_long || seeded || !act;
+      wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(L.cx + 1));
+      wl.best[lane] = kBestInit;
+      wl.second[lane] = 0x7F800000u;
+      wl.runs[kCentreSlot][lane] = make_run(s1, skip1 ? s1 : s2, 0, 0);
+      wave_lds_sync();
+      centre_items = skip1 ? 0u : (s2 - s1 + 3u) >> 2;
+      trips = coop_phase(wl, lane, kCentreSlot, centre_items, tl, hf);
+      const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
+      // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
+      // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
+      // together), instead of eight loads per query up front.
+      float reach = 0.f;
+      if (act && !too_long) {
+        float t;
+        t = fmaxf(qx - margin, 0.f); const float axm = t * t;
+        t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
+        t = fmaxf(qy - margin, 0.f); const float aym = t * t;
+        t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
+        t = fmaxf(qz - margin, 0.f); const float azm = t * t;
+        t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
+        // everything nearer than the best so far can still win; a.gap beyond that is scanned for the certificate's sake
+        const float bnd = fminf(best1, thrf + err);
+        reach = bnd + 4.0f * err;
+        if (a.cert) reach += a.gap * (2.0f * sqrtf(bnd) + a.gap);  // (sqrt(bnd) + gap)^2
+        CellQuad rowq[9];
 #pragma unroll
-      for (int r = 0; r < 9; r++) {
-        if (r == 4) continue;
-        const int dy = r % 3 - 1, dz = r / 3 - 1;
-        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
-        // rows that were not loaded read as empty (all zero); corner reach widens the run to the left / right cell
-        const uint32_t s = (axm + byz <= reach) ? rowq[r].v[0] : rowq[r].v[1];
-        const uint32_t e = (axp + byz <= reach) ? rowq[r].v[3] : rowq[r].v[2];
-        if (s < e) {
-          too_long = too_long || e - s >= kRunMaxLen;
-          wl.runs[nruns][lane] = make_run(s, e, dy, dz);
-          tot += (e - s + 3u) >> 2;
-          nruns++;
+        for (int r = 0; r < 9; r++) {
+          rowq[r].v[0] = rowq[r].v[1] = rowq[r].v[2] = rowq[r].v[3] = 0;
+          if (r == 4) continue;
+          const int dy = r % 3 - 1, dz = r / 3 - 1;
+          const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
+          if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
+        }
+        if (seeded) {  // centre row in one run: centre cell, and the left / right cell where the bound reaches them
+          const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
+          if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
+        } else {
+          if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
+          if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+          if (r == 4) continue;
+          const int dy = r % 3 - 1, dz = r / 3 - 1;
+          const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
+          // rows that were not loaded read as empty (all zero); corner reach widens the run to the left / right cell
+          const uint32_t s = (axm + byz <= reach) ? rowq[r].v[0] : rowq[r].v[1];
+          const uint32_t e = (axp + byz <= reach) ? rowq[r].v[3] : rowq[r].v[2];
+          if (s < e) {
+            too_long = too_long || e - s >= kRunMaxLen;
+            wl.runs[nruns][lane] = make_run(s, e, dy, dz);
+            tot += (e - s + 3u) >> 2;
+            nruns++;
+          }
+        }
+        if (too_long) tot = 0;
+      }
+      wave_lds_sync();
+      trips += coop_phase(wl, lane, 0, tot, tl, hf);
+      if (act) {
+        const unsigned long long bb = wl.best[lane];
+        const float best = __uint_as_float((uint32_t)(bb >> 32)), second = __uint_as_float(wl.second[lane]);
+        bpos = (uint32_t)bb;
+        const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
+        const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
+        if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
+        else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
+        if (verdict != O3D_CORR_PENDING) {
+          // decided in fp32.  Every other point (every point, without a match) is farther than: the runner-up of the
+          // scan (the winner itself without a match), the reach the unscanned cells lie beyond, the edge of the block
+          const float other = (verdict == O3D_CORR_CANDIDATE ? second : best) - err;
+          const float lb2 = fminf(fminf(other, reach), capsq) * (1.0f - 1e-5f);
+          lbn = lb2 > 0.f ? sqrtf(lb2) * (1.0f - 1e-6f) : 0.f;
         }
       }
-      if (too_long) tot = 0;
-    }
-    wave_lds_sync();
-    trips += coop_phase(wl, lane, 0, tot, tl, hf);
-    uint32_t bpos = O3D_POS_NONE;
-    if (inside) {
-      const unsigned long long bb = wl.best[lane];
-      const float best = __uint_as_float((uint32_t)(bb >> 32)), second = __uint_as_float(wl.second[lane]);
-      bpos = (uint32_t)bb;
-      const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
-      const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
-      if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
-      else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
-    }
-    const unsigned long long undecided = __ballot(verdict == O3D_CORR_PENDING);
-    for (unsigned long long m = undecided; m; m &= m - 1) {  // wave-uniform, rare: one undecided query at a time
-      const int srcl = __ffsll((long long)m) - 1;
-      const double qx64 = __shfl(x, srcl, O3D_WAVE), qy64 = __shfl(y, srcl, O3D_WAVE), qz64 = __shfl(z, srcl, O3D_WAVE);
-      const unsigned long long rpb = (unsigned long long)(uintptr_t)rowp;
-      const unsigned long long rq = ((unsigned long long)(uint32_t)__shfl((int)(rpb >> 32), srcl, O3D_WAVE) << 32) |
-                                    (uint32_t)__shfl((int)(uint32_t)rpb, srcl, O3D_WAVE);
-      uint32_t ep = 0;
-      const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
-      if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; }
+      undecided = __ballot(verdict == O3D_CORR_PENDING);
+      for (unsigned long long m = undecided; m; m &= m - 1) {  // wave-uniform, rare: one undecided query at a time
+        const int srcl = __ffsll((long long)m) - 1;
+        const double qx64 = __shfl(x, srcl, O3D_WAVE), qy64 = __shfl(y, srcl, O3D_WAVE), qz64 = __shfl(z, srcl, O3D_WAVE);
+        const unsigned long long rpb = (unsigned long long)(uintptr_t)rowp;
+        const unsigned long long rq = ((unsigned long long)(uint32_t)__shfl((int)(rpb >> 32), srcl, O3D_WAVE) << 32) |
+                                      (uint32_t)__shfl((int)(uint32_t)rpb, srcl, O3D_WAVE);
+        uint32_t ep = 0;
+        const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
+        if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; lbn = 0.f; }  // no bound: searched again next pass
+      }
     }
     // issue the gathers for this trip's candidates; they are consumed in the next trip (or after the loop)
     use_p = verdict == O3D_CORR_CANDIDATE;
+    cert_p = certified;
     i_p = i;
     xs = x; ys = y; zs = z;
-    if (use_p) {
+    if (use_p && !certified) {
       p_p = a.tgt[bpos];
       if (EST != O3D_EST_POINT_TO_POINT) {
         n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
@@ -888,8 +974,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[bpos]; is_p = a.sint[i]; }
     }
     if (a.stats) {
-      const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid));
-      unsigned long long rsum = (unsigned long long)nruns, isum = tot + ((s2 - s1 + 3u) >> 2);
+      const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid)), ncert = __popcll(__ballot(certified));
+      unsigned long long rsum = (unsigned long long)nruns, isum = tot + centre_items;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
         rsum += __shfl_xor(rsum, d, O3D_WAVE);
@@ -902,11 +988,13 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
         atomicAdd(&a.ctr[3], np);
         atomicAdd(&a.ctr[4], isum);
         atomicAdd(&a.ctr[5], nv);
+        atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
       }
     }
     if (valid) {
       if (!use_p) a.corr[i] = verdict;  // a candidate's entry is written when it is confirmed
-      a.pos[i] = use_p ? bpos : O3D_POS_NONE;
+      if (!certified) a.pos[i] = use_p ? bpos : O3D_POS_NONE;  // a certified query keeps its (unchanged) previous match
+      if (a.cert) a.lb[i] = lbn;
     }
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
@@ -1722,6 +1810,10 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
   pa.seed = ctx->use_seed;
+  // the bounds refer to the position of the previous pass: not in hypothesis mode, where every pass starts from the original
+  pa.cert = (ctx->use_cert && !ctx->hyp_mode) ? 1 : 0;
+  pa.gap = (float)(ctx->cert_gap * ctx->gp.h);
+  pa.lb = ctx->lb_sorted;
   pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
   const int est = ctx->estimation;
 #define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \

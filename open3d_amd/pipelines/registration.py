@@ -631,6 +631,14 @@ class IcpSession:
         c.check(c._lib.o3d_icp_profile_read2(c.handle, ms.ctypes.data_as(_lib.c_dp), C.byref(n)))
         return (float(ms[0]), float(ms[1])), n.value
 
+    def profile_read_all(self):
+        """Kernel milliseconds of every recorded pass, in order (call before profile_read / profile_read2, which clear)."""
+        c = self.ctx
+        ms = np.zeros(340)
+        n = C.c_int()
+        c.check(c._lib.o3d_icp_profile_read_all(c.handle, ms.ctypes.data_as(_lib.c_dp), 340, C.byref(n)))
+        return ms[: n.value].copy()
+
     def local_sums_ptr(self):
         return self.ctx._lib.o3d_icp_local_sums(self.ctx.handle)
 

@@ -1,7 +1,7 @@
 """Stress cases for the pruned cell search: queries hugging cell faces, large coordinate offsets, clustered targets."""
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import make_scene, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -170,7 +170,10 @@ def test_seeded_search_walk_on_lattice_with_ties(ctx, oracle):
         return T
 
     walk = [np.eye(4), shift(1, 0, 0), shift(0, -1, 0), shift(0.25, 0, 0), shift(-0.25, 0.5, 0), shift(0, 0, 0.5),
-            shift(7, 3, 0), shift(-7, -3, -0.5), shift(0, 0, 40.0), shift(0, 0, -40.0), shift(0.5, 0.5, 0.5), shift(-1.5, -0.5, -0.5)]
+            shift(7, 3, 0), shift(-7, -3, -0.5), shift(0, 0, 40.0), shift(0, 0, -40.0), shift(0.5, 0.5, 0.5), shift(-1.5, -0.5, -0.5),
+            # small moves: matches certified without a search (k_icp_search_coop) until a bound runs out or a tie forms
+            shift(1e-9, 0, 0), shift(0, 2e-5, -1e-5), shift(1e-3, -1e-3, 0), shift(0.03, 0, 0.01), shift(0.1, 0.05, 0),
+            shift(0.119, -0.049, -0.01), shift(-0.25, 0, 0), shift(0, 0, 0), shift(0, 0, 30.0), shift(1e-6, 0, 0), shift(0, 0, -30.0)]
     for use_tile in (True, False):
         ctx.debug_set(use_tile_search=use_tile)
         sess = reg.IcpSession(ctx).setup(src, tgt, None, r, np.eye(4), reg.TransformationEstimationPointToPoint(),
@@ -197,3 +200,46 @@ def test_staged_copies_back_to_back(ctx):
         bad = C.c_int64(-1)
         ctx.check(ctx._lib.o3d_debug_copy_check(ctx.handle, (mb << 20) + 24, 3, C.byref(bad)))
         assert bad.value == 0, "%d MiB: %d words differ" % (mb, bad.value)
+
+
+def test_certified_matches_skip_the_search_and_change_nothing(ctx, oracle):
+    """Near convergence k_icp_search_coop certifies most previous matches without a search (distance to the match below the
+    carried lower bound on every other target point).  The loop with certificates must give, pass for pass, what the loop
+    without them gives -- the same correspondence count and sum of squared distances to the last bit -- and the final
+    correspondences must equal the oracle's; the counters must show that the certificates were actually used, also for
+    the queries WITHOUT a match of a partially overlapping pair."""
+    import os
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(120_000, 100_000, cfg_id=21, theta_deg=0.3)
+    s = sc["spacing"]
+    src = sc["source"].copy()
+    src[:30000, 0] += 240.0                   # a quarter of the source lies far outside the target's grid: no match, ever
+    src[30000:40000, 2] += 3.0 * s            # ... and some hover 1.5 radii above the surface: inside the grid, no match
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    est, crit = reg.TransformationEstimationPointToPlane(), reg.ICPConvergenceCriteria(0, 0, 24)
+    logs, finals, stats = {}, {}, {}
+    for mode in ("cert", "nocert"):
+        os.environ.pop("O3D_NO_CERT", None)
+        if mode == "nocert":
+            os.environ["O3D_NO_CERT"] = "1"
+        try:
+            ctx.debug_set(collect_tile_stats=True)
+            ctx.tile_stats(reset=True)
+            sess = reg.IcpSession(ctx).setup(src, sc["target"], nrm, 2 * s, np.eye(4), est, crit)
+            sess.run()
+            finals[mode] = sess.finish()
+            logs[mode] = sess.log()
+            stats[mode] = ctx.tile_stats(reset=True)
+        finally:
+            os.environ.pop("O3D_NO_CERT", None)
+            ctx.debug_set(collect_tile_stats=False)
+    a, b = logs["cert"], logs["nocert"]
+    assert a.shape == b.shape and a.shape[0] == 25
+    assert np.array_equal(a[:, 2], b[:, 2]) and np.array_equal(a[:, 3], b[:, 3])    # n_corr and sum d2 of every pass
+    assert np.array_equal(a[:, 4:20], b[:, 4:20])                                    # the transformation before every pass
+    assert np.array_equal(finals["cert"].corr_, finals["nocert"].corr_)
+    ref = oracle.registration_icp(src, sc["target"], 2 * s, None, 2, nrm, rel_fitness=0.0, rel_rmse=0.0, max_iter=24)
+    assert np.array_equal(finals["cert"].corr_, ref.corr)
+    assert stats["nocert"]["certified"] == 0
+    assert stats["cert"]["certified"] > 8 * len(src), stats["cert"]       # most queries in most of the later passes
+    assert stats["cert"]["item_trips"] < 0.6 * stats["nocert"]["item_trips"]
