@@ -287,9 +287,11 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   ctx->stream = ctx->own_stream;
   if ((e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   if ((e = hipMalloc((void **)&ctx->state, sizeof(IcpState))) != hipSuccess) return bail(e, "hipMalloc state");
-  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
+  // rows of the search kernel (or of any other per-workgroup reduction), then the rows of k_icp_cert
+  if ((e = hipMalloc((void **)&ctx->partials, sizeof(double) * O3D_NSUMS * 2 * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc partials");
   if ((e = hipMalloc((void **)&ctx->sums, sizeof(double) * O3D_NSUMS)) != hipSuccess) return bail(e, "hipMalloc sums");
   if ((e = hipMalloc((void **)&ctx->counters, sizeof(unsigned long long) * O3D_NCOUNTERS)) != hipSuccess) return bail(e, "hipMalloc counters");
+  if ((e = hipMalloc((void **)&ctx->work_count, sizeof(uint32_t) * 8 * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc work_count");
   if ((e = hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
   // the scratch address of o3d_compute_transformation_noalloc on this device, so that its first call may come under capture
   if (o3d_noalloc_prepare_device(device_id) != O3D_OK) return bail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
@@ -305,7 +307,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
-                  ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
+                  ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
                   ctx->counters};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -449,6 +451,15 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
   }
   ctx->search_grid = (int)gs;
+  // k_icp_cert runs on the same grid by default (its pass is bound by memory traffic, not by occupancy: 1536 and 2048
+  // workgroups measured 7 % and 5 % slower).  The two kernels walk the same segments of the source (o3d_launch_pass), so
+  // other grids stay possible: O3D_CERT_GRID = 1536 or 2048, tuning aid.
+  int64_t gc = gs;
+  if (const char *e = getenv("O3D_CERT_GRID")) {
+    const long v = atol(e);
+    if (gs == O3D_NUM_CU * 4 && (v == 1536 || v == 2048) && g >= v) gc = v;
+  }
+  ctx->cert_grid = (int)gc;
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
   ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : 1;  // tuning aid
   if (const char *e = getenv("O3D_CERT_GAP")) {
@@ -476,7 +487,15 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   hs->estimation = estimation;
   hs->with_scaling = with_scaling;
   // fixed origin for the Umeyama moments: centre of the target's bounding box (cuts cancellation, any value is valid)
-  for (int d = 0; d < 3; d++) hs->centre[d] = ctx->gp.gmin[d] + 0.5 * ctx->gp.h * (double)(d == 0 ? ctx->gp.nx : (d == 1 ? ctx->gp.ny : ctx->gp.nz));
+  double diag2 = 0.0;
+  for (int d = 0; d < 3; d++) {
+    const double ext = ctx->gp.h * (double)(d == 0 ? ctx->gp.nx : (d == 1 ? ctx->gp.ny : ctx->gp.nz));
+    hs->centre[d] = ctx->gp.gmin[d] + 0.5 * ext;
+    diag2 += 0.25 * ext * ext;
+  }
+  hs->radius = sqrt(diag2);
+  // certificates hold while a query moves less than about half the slack its bound was given (the search's extra reach)
+  hs->cert_skip_above = 0.5 * ctx->cert_gap * ctx->gp.h;
   O3D_HIP(ctx, o3d_h2d(ctx, ctx->state, hs, sizeof(IcpState)));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   float ms0 = 0, ms1 = 0;

@@ -444,8 +444,10 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     if (ctx->corr_out) (void)hipFree(ctx->corr_out);
     if (ctx->pos_sorted) (void)hipFree(ctx->pos_sorted);
     if (ctx->lb_sorted) (void)hipFree(ctx->lb_sorted);
+    if (ctx->work) (void)hipFree(ctx->work);
     ctx->pos_sorted = nullptr;
     ctx->lb_sorted = nullptr;
+    ctx->work = nullptr;
     ctx->src_sorted = nullptr; ctx->src_perm = nullptr; ctx->corr_sorted = nullptr; ctx->corr_out = nullptr;
     ctx->cap_src = 0;
     O3D_HIP(ctx, hipMalloc((void **)&ctx->src_sorted, sizeof(double) * 3 * nn));
@@ -454,6 +456,8 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     O3D_HIP(ctx, hipMalloc((void **)&ctx->corr_out, sizeof(int32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->pos_sorted, sizeof(uint32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->lb_sorted, sizeof(float) * nn));
+    // k_icp_cert's chunks are rounded up to whole wavefronts: a segment may start (not reach) beyond n
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->work, sizeof(uint32_t) * (nn + 4 * O3D_BLOCK)));
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;

@@ -284,9 +284,15 @@ struct PassArgs {
   int32_t *corr;   // per processing position: target index, or -1 none
   uint32_t *pos;   // per processing position: position of the match in tgt_sorted (O3D_POS_NONE: none)
   int seed;        // k_icp_search_coop: use the previous pass's match as the first pruning bound
-  int cert;        // k_icp_search_coop: skip the search of a query whose previous match is certified to be its nearest still
-  float gap;       // ... and scan this far beyond the best distance, so that the bounds have slack (absolute length)
+  int listed;      // k_icp_search_coop: search the work list of k_icp_cert only (unless IcpState::skip_cert)
+  float gap;       // k_icp_search_coop: scan this far beyond the best distance, so that the bounds have slack (absolute length)
   float *lb;       // per processing position: lower bound on the distance to every target point but the match
+  uint32_t *work;        // work list: per wavefront, from the start of its range, the positions k_icp_cert could not certify
+  uint32_t *work_count;  // per segment
+  int64_t seg_len;       // positions per segment (a multiple of 64)
+  int segs_per_wave;     // k_icp_search_coop: segments per wavefront
+  int segs_per_wave_cert;  // k_icp_cert: segments per wavefront (the two grids differ, the segments are common)
+  int cert_row0;   // first partial row of k_icp_cert (the rows of k_icp_search_coop come first)
   double *partials;
   double thr;
   // coloured ICP only (ColoredICP.cpp:125-177)
@@ -299,12 +305,19 @@ struct PassArgs {
 #define O3D_CORR_PENDING (-2)
 #define O3D_CORR_CANDIDATE (-3)
 
+// A value that is the same in every lane, moved to scalar registers (the compiler keeps loads from the loop state in
+// vector registers otherwise: 32 of them for the update matrix alone).
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void load_update(const IcpState *st, double (&T)[12], double (&w)[4]) {
 #pragma unroll
   for (int c = 0; c < 4; c++) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) T[c * 3 + r] = st->update[c * 4 + r];  // element (r, c) at T[c * 3 + r]
-    w[c] = st->update[c * 4 + 3];
+    for (int r = 0; r < 3; r++) T[c * 3 + r] = uniform_f64(st->update[c * 4 + r]);  // element (r, c) at T[c * 3 + r]
+    w[c] = uniform_f64(st->update[c * 4 + 3]);
   }
 }
 
@@ -403,11 +416,16 @@ __device__ __forceinline__ void mfma_rank64(VBuf &vb, int lane, const double (&v
   wave_lds_sync();
   const int comp = lane & 15, k = lane >> 4;
   const double *col = &vb.v[comp < kVComp ? comp : 0][k];
+  // operands in batches of four (eight registers in flight instead of thirty-two, which would cost the kernels around this
+  // call their occupancy or push them into scratch memory)
 #pragma unroll
-  for (int m = 0; m < 16; m++) {
-    double a = col[4 * m];
-    if (comp >= kVComp) a = 0.0;
-    S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, S, 0, 0, 0);
+  for (int m0 = 0; m0 < 16; m0 += 4) {
+    double a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = comp >= kVComp ? 0.0 : col[4 * (m0 + u)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) S = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], a[u], S, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   wave_lds_sync();
 }
@@ -699,6 +717,135 @@ __device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tg
   return found != 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Certificates.  Next to its match m every query keeps lb, a lower bound on its distance to every target point OTHER
+// than m (to every target point when it has no match), valid at the position the bound was last written for.  A pass
+// moves the query by |dq|, so lb - |dq| bounds the same distances at the new position; while the new distance to m stays
+// below that, m is still the unique nearest point and no search is needed -- the exact fp64 distance to m, the radius test
+// and the sums are computed as always, so the result is what a search would give, bit for bit.  Near convergence this is
+// nearly every query of nearly every pass.  lb comes out of a search for free: the runner-up among the scanned candidates
+// and the pruning reach (every cell the walk left out is farther than that), which PassArgs::gap widens beyond the
+// winner's distance so that a bound has room to shrink.  All bounds are fp32, rounded towards "certificate fails" with a
+// relative slack of 1e-6 -- nine orders of magnitude above the rounding of the fp64 distances they stand for -- so equal
+// distances (ties) can never be certified.
+//
+// A pass with certificates is two launches:
+//   k_icp_cert          streams the source: update in place, certificate, sums of the certified matches on the matrix
+//                       cores; the queries it cannot certify go to a work list (one segment per wavefront, in order, so
+//                       that every sum is added in the same order run after run)
+//   k_icp_search_coop   the cooperative search over the work list only.
+// IcpState::skip_cert (set by the estimate that produced the pending update, from the distance that update moves the
+// cloud) turns the first launch into a no-op when the bounds cannot hold anyway; the search then runs over everything,
+// as it does in the first pass.
+
+// The wavefront's share of the source.  The source is cut into segments of PassArgs::seg_len positions (a multiple of 64);
+// wavefront `wave` of the workgroup that owns chunk c -- workgroup -> chunk is XCD-aware, see k_icp_search -- takes the
+// `m` consecutive segments from slot * m on, slot = c * 4 + wave.  k_icp_cert runs with m = 1 on a grid m' times that of
+// k_icp_search_coop, which takes m' segments per wavefront: both walk the same segments, the work list and its counters
+// are per segment.
+struct WaveRange {
+  unsigned chunk;
+  unsigned seg0;     // first segment
+  int64_t beg, end;  // positions [beg, end) of all m segments
+};
+__device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, int m) {
+  WaveRange r;
+  r.chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  r.seg0 = (r.chunk * 4u + (threadIdx.x >> 6)) * (unsigned)m;
+  r.beg = (int64_t)r.seg0 * seg_len;
+  r.end = r.beg + (int64_t)m * seg_len;
+  if (r.end > n_src) r.end = n_src;
+  if (r.beg > r.end) r.beg = r.end;
+  return r;
+}
+
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
+  if (a.st->done) return;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
+  static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const WaveRange wr = wave_range(a.n_src, a.seg_len, a.segs_per_wave_cert);
+  if (a.st->skip_cert) {  // the pending update moves the cloud farther than any bound reaches: everything is searched
+    if (tid < O3D_NSUMS) a.partials[((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid] = 0.0;
+    return;
+  }
+  VBuf &vb = reinterpret_cast<VBuf *>(lds_raw)[tid >> 6];
+  const double cx0 = uniform_f64(a.st->centre[0]), cy0 = uniform_f64(a.st->centre[1]), cz0 = uniform_f64(a.st->centre[2]);
+  const int apply = a.st->apply_update;
+  double T[12], w[4];
+  load_update(a.st, T, w);
+  const float thrf = (float)a.thr;
+  v4f64 S = {0.0, 0.0, 0.0, 0.0};
+  unsigned long long ncert = 0;
+  for (int sg = 0; sg < a.segs_per_wave_cert; sg++) {
+  const int64_t sbeg = wr.beg + (int64_t)sg * a.seg_len;
+  const int64_t send = sbeg + a.seg_len < wr.end ? sbeg + a.seg_len : wr.end;
+  uint32_t nwork = 0;  // wave-uniform
+  for (int64_t base = sbeg; base < send; base += O3D_WAVE) {
+    const int64_t i = base + lane;
+    const bool valid = i < send;
+    double x = 0, y = 0, z = 0;
+    uint32_t pprev = O3D_POS_NONE;
+    float lbv = 0.f, moved = 0.f;
+    if (valid) {
+      pprev = a.pos[i];
+      lbv = a.lb[i];
+    }
+    if (valid) { x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2]; }
+    const bool has_prev = valid && pprev != O3D_POS_NONE;
+    double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, is = 0.0;
+    if (has_prev) {
+      p = a.tgt[pprev];
+      if (EST != O3D_EST_POINT_TO_POINT) {
+        n0 = a.nrm[3 * (size_t)pprev]; n1 = a.nrm[3 * (size_t)pprev + 1]; n2 = a.nrm[3 * (size_t)pprev + 2];
+      }
+      if (EST == O3D_EST_COLORED_ICP) { tc = a.tcol[pprev]; is = a.sint[i]; }
+    }
+    if (valid && apply) {
+      const double xo = x, yo = y, zo = z;
+      apply_update(T, w, x, y, z);
+      a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
+      const double mx = x - xo, my = y - yo, mz = z - zo;
+      moved = sqrtf((float)(mx * mx + my * my + mz * mz)) * (1.0f + 1e-6f);  // NaN for a non-finite point: never certified
+    }
+    // what the stored bound is still worth at the new position (<= 0, or NaN: nothing)
+    const float lbc = lbv * (1.0f - 1e-6f) - moved;
+    double d2 = 0.0;
+    if (has_prev) {
+      const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
+      d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+    }
+    bool certified = false;
+    if (valid && lbc > 0.f) {
+      const float lb2 = lbc * lbc * (1.0f - 1e-6f);
+      certified = has_prev ? (float)d2 * (1.0f + 1e-6f) < lb2   // m is strictly nearer than everything else
+                           : lb2 > thrf * (1.0f + 1e-6f);        // nothing within the radius
+    }
+    // m is the nearest point whatever its distance: beyond the radius it simply is no correspondence (Registration.cpp:64-66)
+    const bool use = certified && has_prev && d2 < a.thr;
+    if (certified) {
+      a.corr[i] = use ? (int32_t)__double_as_longlong(p.w) : O3D_CORR_NONE;
+      a.lb[i] = lbc;
+    }
+    const unsigned long long need = __ballot(valid && !certified);
+    if (valid && !certified) a.work[sbeg + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    nwork += (uint32_t)__popcll(need);
+    if (a.stats) ncert += __popcll(__ballot(certified));
+    push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
+  }
+  if (lane == 0) a.work_count[wr.seg0 + sg] = nwork;
+  }
+  if (lane == 0 && a.stats && ncert) atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
+  __syncthreads();  // every wavefront is done with its staging buffer
+  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
+}
+
+// The cooperative search (see above CoopWave).  PassArgs::listed: the queries are the work list k_icp_cert left behind
+// (already moved by the pending update), unless IcpState::skip_cert says that k_icp_cert stood aside.
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
 template <int EST>
@@ -708,20 +855,21 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   CoopWave &wl = wls[tid >> 6];
-  const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
+  const double cx0 = uniform_f64(a.st->centre[0]), cy0 = uniform_f64(a.st->centre[1]), cz0 = uniform_f64(a.st->centre[2]);
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
-  const int apply = a.st->apply_update;
+  const bool listed = a.listed && !a.st->skip_cert;
+  const int apply = listed ? 0 : a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-  const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
-  const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int64_t beg = (int64_t)chunk * per;
-  const int64_t end = beg + per < a.n_src ? beg + per : a.n_src;
+  const int nseg = listed ? a.segs_per_wave : 1;  // listed: one work-list segment after the other; else the whole range at once
+  const WaveRange wr = wave_range(a.n_src, a.seg_len, a.segs_per_wave);
   const float hf = (float)gp.h;
   const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
   const float margin = 1e-5f * hf;
   const float seed_max = kSeedMax * hf * hf;
+  const float cap = hf * (1.0f - 1e-6f);  // every point outside the 3x3x3 block, or around a query outside the grid interior
+  const float capsq = cap * cap;
   const float4 *__restrict__ tl = a.tgt_local;
   const uint32_t *__restrict__ cs = a.cell_start;
   const unsigned long long kBestInit = (unsigned long long)0x7F800000u << 32;  // +inf, position 0
@@ -729,12 +877,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
 
   // The fp32 winner is confirmed in fp64 with the arithmetic of the exact search (it then IS the exact result: every
   // other candidate is farther by more than the fp32 error bound), and its terms of the next estimate go to the matrix
-  // cores.  What is not decisive in fp32 is searched again in fp64 on the spot (exact_block_search).  The gathers of the
-  // matched target point and normal
-  // are issued at the end of a trip and consumed in the next one, behind that trip's own source loads, so that their
-  // latency is not exposed.
-  bool use_p = false;   // carried from the previous trip
-  bool cert_p = false;  // ... its candidate is a certified previous match (may lie beyond the radius: not a violation)
+  // cores.  What is not decisive in fp32 is searched again in fp64 on the spot (wave_exact_search).  The gathers of the
+  // matched target point and normal are issued at the end of a trip and consumed in the next one, behind that trip's own
+  // source loads, so that their latency is not exposed.
+  bool use_p = false;  // carried from the previous trip
   int64_t i_p = 0;
   double4 p_p = make_double4(0.0, 0.0, 0.0, 0.0), tc_p = make_double4(0.0, 0.0, 0.0, 0.0);
   double n0_p = 0.0, n1_p = 0.0, n2_p = 0.0, xs = 0.0, ys = 0.0, zs = 0.0, is_p = 0.0;
@@ -749,10 +895,9 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     }
     // A confirmation that fails would mean that the fp32 error bound does not hold (winners near the threshold were
     // resolved exactly before they got here).  It is counted; o3d_icp_finish / o3d_icp_fetch then fail loudly instead of
-    // returning a result that might not be exact.  (A certified previous match is the nearest point whatever its
-    // distance: beyond the radius it simply is no correspondence, Registration.cpp:64-66.)
+    // returning a result that might not be exact.
     if (use_p && !(d2 < a.thr)) {
-      if (!cert_p) atomicAdd(&a.ctr[O3D_CTR_VIOLATIONS], 1ull);
+      atomicAdd(&a.ctr[O3D_CTR_VIOLATIONS], 1ull);
       use_p = false;
     }
     if (had_p) a.corr[i_p] = use_p ? (int32_t)__double_as_longlong(p_p.w) : O3D_CORR_NONE;
@@ -760,213 +905,150 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     push_sums<EST>(wl.vb, lane, S, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0, tc_p, is_p, a.slg, a.slp);
   };
 
-  // Certificates (a.cert).  Next to its match m every query keeps lb, a lower bound on its distance to every target point
-  // OTHER than m (to every target point when it has no match), valid at the position the bound was last written for.  A
-  // pass moves the query by |dq|, so lb - |dq| bounds the same distances at the new position; while the new distance to
-  // m stays below that, m is still the unique nearest point and the search is skipped altogether -- the exact fp64
-  // distance to m, the radius test and the sums are computed as always.  Near convergence this is nearly every query.
-  // lb comes out of a search for free: the runner-up of the scanned candidates and the pruning reach (every cell the walk
-  // left out is farther than that), which a.gap widens beyond the winner's distance so that a bound has room to shrink.
-  // All bounds are fp32 rounded towards "certificate fails" with relative slack 1e-6, nine orders of magnitude above the
-  // rounding of the fp64 distances they stand for; equal distances (ties) can therefore never be certified.
-  const float cap = hf * (1.0f - 1e-6f);  // every point outside the 3x3x3 block, or around a query outside the grid interior
-  const float capsq = cap * cap;
-
-  struct Loc {
-    int cx, cy, cz;
-    bool inside;
-    float qx, qy, qz;
-    uint32_t s0, s1, s2, s3;
-    const uint32_t *rowp;
-  };
-  auto locate = [&](bool valid, double x, double y, double z) {
-    Loc L;
-    L.cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
-    L.cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
-    L.cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
-    L.inside = valid && L.cx >= 0 && L.cx < gp.nx && L.cy >= 1 && L.cy < gp.ny - 1 && L.cz >= 1 && L.cz < gp.nz - 1;
-    L.qx = L.qy = L.qz = 0.f;
-    L.s0 = L.s1 = L.s2 = L.s3 = 0;
-    L.rowp = cs;
-    if (L.inside) {
-      L.qx = (float)((x - gp.gmin[0]) - (double)L.cx * gp.h);
-      L.qy = (float)((y - gp.gmin[1]) - (double)L.cy * gp.h);
-      L.qz = (float)((z - gp.gmin[2]) - (double)L.cz * gp.h);
-      L.rowp = cs + (((uint32_t)L.cz * (uint32_t)gp.ny + (uint32_t)L.cy) * (uint32_t)gp.nxp + (uint32_t)L.cx);
-      const CellQuad qc = *reinterpret_cast<const CellQuad *>(L.rowp);
-      L.s0 = qc.v[0]; L.s1 = qc.v[1]; L.s2 = qc.v[2]; L.s3 = qc.v[3];
-    }
-    return L;
-  };
-
-  for (int64_t base = beg; base < end; base += O3D_BLOCK) {  // block-uniform trip count
-    const int64_t i = base + tid;
-    const bool valid = i < end;
+  bool first = true;
+  for (int sg = 0; sg < nseg; sg++) {
+  const int64_t sbeg = wr.beg + (int64_t)sg * a.seg_len;
+  const int64_t nq = listed ? (sbeg < wr.end ? (int64_t)a.work_count[wr.seg0 + sg] : 0) : wr.end - wr.beg;  // wave-uniform
+  for (int64_t k0 = 0; k0 < nq; k0 += O3D_WAVE) {  // wave-uniform trip count
+    const bool valid = k0 + lane < nq;
+    int64_t i = sbeg + k0 + lane;
+    if (listed && valid) i = a.work[i];
     double x = 0, y = 0, z = 0;
     uint32_t pprev = O3D_POS_NONE;
-    float lbv = 0.f, moved = 0.f;
     if (valid) {
       x = a.src_in[3 * i]; y = a.src_in[3 * i + 1]; z = a.src_in[3 * i + 2];
-      if (a.seed || a.cert) pprev = a.pos[i];
-      if (a.cert) lbv = a.lb[i];
+      if (a.seed) pprev = a.pos[i];
     }
     if (valid && apply) {
-      const double xo = x, yo = y, zo = z;
       apply_update(T, w, x, y, z);
       a.src[3 * i] = x; a.src[3 * i + 1] = y; a.src[3 * i + 2] = z;
-      const double mx = x - xo, my = y - yo, mz = z - zo;
-      moved = sqrtf((float)(mx * mx + my * my + mz * mz)) * (1.0f + 1e-6f);  // NaN for a non-finite point: never certified
     }
-    // what the stored bound is still worth at the new position (<= 0, or NaN: worth nothing)
-    const float lbc = lbv * (1.0f - 1e-6f) - moved;
-    const bool has_prev = valid && pprev != O3D_POS_NONE;
-    // The target point this query matched in the previous pass: the certificate's point, and otherwise the seed.  Any
-    // target point bounds the nearest-neighbour distance from above; near convergence the previous match is (nearly) the
-    // nearest, so its exact distance prunes the block from the start and the centre-cell phase is skipped.  As a seed it
-    // is only a bound: every cell it leaves is scanned and the winner comes out of the scan as always.
-    double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (has_prev) ps = a.tgt[pprev];
-    // When every lane still holds a positive bound the wavefront will most likely skip the search: the cell table is then
-    // not touched up front (and, in the rare case that a certificate fails after all, loaded one latency later).
-    const bool optimistic = a.cert && __ballot(valid && !(lbc > 0.f)) == 0ull;
-    Loc L;
-    if (!optimistic) L = locate(valid, x, y, z);
-    if (base != beg) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
-    double d2m = 0.0;
-    if (has_prev) {
-      const double ddx = x - ps.x, ddy = y - ps.y, ddz = z - ps.z;
-      d2m = ddx * ddx + ddy * ddy + ddz * ddz;
-    }
-    bool certified = false;
-    if (a.cert && valid && lbc > 0.f) {
-      const float lb2 = lbc * lbc * (1.0f - 1e-6f);
-      certified = has_prev ? (float)d2m * (1.0f + 1e-6f) < lb2   // m is strictly nearer than everything else
-                           : lb2 > thrf * (1.0f + 1e-6f);         // nothing within the radius
-    }
+    const int cx = o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx);
+    const int cy = o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny);
+    const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
+    const bool inside = valid && cx >= 0 && cx < gp.nx && cy >= 1 && cy < gp.ny - 1 && cz >= 1 && cz < gp.nz - 1;
     int32_t verdict = O3D_CORR_NONE;
-    uint32_t bpos = O3D_POS_NONE;
-    float lbn = certified ? lbc : 0.f;  // the bound written for the next pass
-    unsigned trips = 0;
-    int nruns = 0;
-    uint32_t tot = 0, centre_items = 0;
-    unsigned long long undecided = 0ull;
-    if (certified && has_prev) {
-      // the previous trip's candidate has been consumed: its registers take this one right away, and the gathers of a
-      // certified match run behind whatever the rest of the wavefront still has to search
-      verdict = O3D_CORR_CANDIDATE;
-      bpos = pprev;
-      p_p = ps;
-      if (EST != O3D_EST_POINT_TO_POINT) {
-        n0_p = a.nrm[3 * (size_t)pprev]; n1_p = a.nrm[3 * (size_t)pprev + 1]; n2_p = a.nrm[3 * (size_t)pprev + 2];
-      }
-      if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[pprev]; is_p = a.sint[i]; }
+    float qx = 0, qy = 0, qz = 0;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const uint32_t *rowp = cs;
+    if (inside) {
+      qx = (float)((x - gp.gmin[0]) - (double)cx * gp.h);
+      qy = (float)((y - gp.gmin[1]) - (double)cy * gp.h);
+      qz = (float)((z - gp.gmin[2]) - (double)cz * gp.h);
+      rowp = cs + (((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx);
+      const CellQuad qc = *reinterpret_cast<const CellQuad *>(rowp);
+      s0 = qc.v[0]; s1 = qc.v[1]; s2 = qc.v[2]; s3 = qc.v[3];
     }
-    if (__ballot(valid && !certified) != 0ull) {  // wave-uniform: somebody has to search
-      if (optimistic) L = locate(valid, x, y, z);
-      const bool act = L.inside && !certified;
-      if (valid && !certified && !L.inside) lbn = cap;  // at least one cell from every target point
-      const uint32_t s0 = L.s0, s1 = L.s1, s2 = L.s2, s3 = L.s3;
-      const float qx = L.qx, qy = L.qy, qz = L.qz;
-      const uint32_t *rowp = L.rowp;
-      bool too_long = s3 - s0 >= kRunMaxLen;
-      float seedb = INFINITY;
-      if (a.seed && act && has_prev) seedb = (float)d2m * 1.000001f + err;  // >= the exact distance, in fp32
-      const bool seeded = seedb <= seed_max && !too_long;
-      // phase 1: the centre cells of the wavefront's queries that have no usable seed
-      const bool skip1 = too_long || seeded || !act;
-      wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(L.cx + 1));
-      wl.best[lane] = kBestInit;
-      wl.second[lane] = 0x7F800000u;
-      wl.runs[kCentreSlot][lane] = make_run(s1, skip1 ? s1 : s2, 0, 0);
-      wave_lds_sync();
-      centre_items = skip1 ? 0u : (s2 - s1 + 3u) >> 2;
-      trips = coop_phase(wl, lane, kCentreSlot, centre_items, tl, hf);
-      const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
-      // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
-      // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
-      // together), instead of eight loads per query up front.
-      float reach = 0.f;
-      if (act && !too_long) {
-        float t;
-        t = fmaxf(qx - margin, 0.f); const float axm = t * t;
-        t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
-        t = fmaxf(qy - margin, 0.f); const float aym = t * t;
-        t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
-        t = fmaxf(qz - margin, 0.f); const float azm = t * t;
-        t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
-        // everything nearer than the best so far can still win; a.gap beyond that is scanned for the certificate's sake
-        const float bnd = fminf(best1, thrf + err);
-        reach = bnd + 4.0f * err;
-        if (a.cert) reach += a.gap * (2.0f * sqrtf(bnd) + a.gap);  // (sqrt(bnd) + gap)^2
-        CellQuad rowq[9];
+    // Seed: the target point this query matched in the previous pass.  Any target point bounds the nearest-neighbour
+    // distance from above; near convergence the previous match is (nearly) the nearest, so its exact distance prunes
+    // the block from the start and the centre-cell phase is skipped.  Only a bound: every cell it leaves is scanned and
+    // the winner comes out of the scan as always.
+    const bool has_seed = inside && pprev != O3D_POS_NONE;
+    double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (has_seed) ps = a.tgt[pprev];
+    if (!first) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
+    first = false;
+    bool too_long = s3 - s0 >= kRunMaxLen;
+    float seedb = INFINITY;
+    if (has_seed) {
+      const double ddx = x - ps.x, ddy = y - ps.y, ddz = z - ps.z;
+      seedb = (float)(ddx * ddx + ddy * ddy + ddz * ddz) * 1.000001f + err;  // >= the exact distance, in fp32
+    }
+    const bool seeded = seedb <= seed_max && !too_long;
+    // phase 1: the centre cells of the wavefront's queries that have no usable seed
+    wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(cx + 1));
+    wl.best[lane] = kBestInit;
+    wl.second[lane] = 0x7F800000u;
+    wl.runs[kCentreSlot][lane] = make_run(s1, (too_long || seeded) ? s1 : s2, 0, 0);
+    wave_lds_sync();
+    unsigned trips = coop_phase(wl, lane, kCentreSlot, (too_long || seeded) ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
+    const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
+    // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
+    // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
+    // together), instead of eight loads per query up front.
+    int nruns = 0;
+    uint32_t tot = 0;
+    float reach = 0.f;
+    if (inside && !too_long) {
+      float t;
+      t = fmaxf(qx - margin, 0.f); const float axm = t * t;
+      t = fmaxf(hf - qx - margin, 0.f); const float axp = t * t;
+      t = fmaxf(qy - margin, 0.f); const float aym = t * t;
+      t = fmaxf(hf - qy - margin, 0.f); const float ayp = t * t;
+      t = fmaxf(qz - margin, 0.f); const float azm = t * t;
+      t = fmaxf(hf - qz - margin, 0.f); const float azp = t * t;
+      // everything nearer than the best so far can still win; gap beyond that is scanned for the certificates' sake
+      const float bnd = fminf(best1, thrf + err);
+      reach = bnd + 4.0f * err + a.gap * (2.0f * sqrtf(bnd) + a.gap);  // (sqrt(bnd) + gap)^2, gap = 0 without certificates
+      CellQuad rowq[9];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-          rowq[r].v[0] = rowq[r].v[1] = rowq[r].v[2] = rowq[r].v[3] = 0;
-          if (r == 4) continue;
-          const int dy = r % 3 - 1, dz = r / 3 - 1;
-          const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
-          if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
-        }
-        if (seeded) {  // centre row in one run: centre cell, and the left / right cell where the bound reaches them
-          const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
-          if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
-        } else {
-          if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
-          if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
-        }
+      for (int r = 0; r < 9; r++) {
+        rowq[r].v[0] = rowq[r].v[1] = rowq[r].v[2] = rowq[r].v[3] = 0;
+        if (r == 4) continue;
+        const int dy = r % 3 - 1, dz = r / 3 - 1;
+        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
+        if (byz <= reach) rowq[r] = *reinterpret_cast<const CellQuad *>(rowp + (dy * row_y + dz * row_z));
+      }
+      if (seeded) {  // centre row in one run: centre cell, and the left / right cell where the bound reaches them
+        const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
+        if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
+      } else {
+        if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
+        if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
+      }
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-          if (r == 4) continue;
-          const int dy = r % 3 - 1, dz = r / 3 - 1;
-          const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
-          // rows that were not loaded read as empty (all zero); corner reach widens the run to the left / right cell
-          const uint32_t s = (axm + byz <= reach) ? rowq[r].v[0] : rowq[r].v[1];
-          const uint32_t e = (axp + byz <= reach) ? rowq[r].v[3] : rowq[r].v[2];
-          if (s < e) {
-            too_long = too_long || e - s >= kRunMaxLen;
-            wl.runs[nruns][lane] = make_run(s, e, dy, dz);
-            tot += (e - s + 3u) >> 2;
-            nruns++;
-          }
-        }
-        if (too_long) tot = 0;
-      }
-      wave_lds_sync();
-      trips += coop_phase(wl, lane, 0, tot, tl, hf);
-      if (act) {
-        const unsigned long long bb = wl.best[lane];
-        const float best = __uint_as_float((uint32_t)(bb >> 32)), second = __uint_as_float(wl.second[lane]);
-        bpos = (uint32_t)bb;
-        const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
-        const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
-        if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
-        else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
-        if (verdict != O3D_CORR_PENDING) {
-          // decided in fp32.  Every other point (every point, without a match) is farther than: the runner-up of the
-          // scan (the winner itself without a match), the reach the unscanned cells lie beyond, the edge of the block
-          const float other = (verdict == O3D_CORR_CANDIDATE ? second : best) - err;
-          const float lb2 = fminf(fminf(other, reach), capsq) * (1.0f - 1e-5f);
-          lbn = lb2 > 0.f ? sqrtf(lb2) * (1.0f - 1e-6f) : 0.f;
+      for (int r = 0; r < 9; r++) {
+        if (r == 4) continue;
+        const int dy = r % 3 - 1, dz = r / 3 - 1;
+        const float byz = (dz < 0 ? azm : (dz > 0 ? azp : 0.f)) + (dy < 0 ? aym : (dy > 0 ? ayp : 0.f));
+        // rows that were not loaded read as empty (all zero); corner reach widens the run to the left / right cell
+        const uint32_t s = (axm + byz <= reach) ? rowq[r].v[0] : rowq[r].v[1];
+        const uint32_t e = (axp + byz <= reach) ? rowq[r].v[3] : rowq[r].v[2];
+        if (s < e) {
+          too_long = too_long || e - s >= kRunMaxLen;
+          wl.runs[nruns][lane] = make_run(s, e, dy, dz);
+          tot += (e - s + 3u) >> 2;
+          nruns++;
         }
       }
-      undecided = __ballot(verdict == O3D_CORR_PENDING);
-      for (unsigned long long m = undecided; m; m &= m - 1) {  // wave-uniform, rare: one undecided query at a time
-        const int srcl = __ffsll((long long)m) - 1;
-        const double qx64 = __shfl(x, srcl, O3D_WAVE), qy64 = __shfl(y, srcl, O3D_WAVE), qz64 = __shfl(z, srcl, O3D_WAVE);
-        const unsigned long long rpb = (unsigned long long)(uintptr_t)rowp;
-        const unsigned long long rq = ((unsigned long long)(uint32_t)__shfl((int)(rpb >> 32), srcl, O3D_WAVE) << 32) |
-                                      (uint32_t)__shfl((int)(uint32_t)rpb, srcl, O3D_WAVE);
-        uint32_t ep = 0;
-        const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
-        if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; lbn = 0.f; }  // no bound: searched again next pass
+      if (too_long) tot = 0;
+    }
+    wave_lds_sync();
+    trips += coop_phase(wl, lane, 0, tot, tl, hf);
+    uint32_t bpos = O3D_POS_NONE;
+    float lbn = (valid && !inside) ? cap : 0.f;  // the bound left for the certificates; outside: a cell from every target point
+    if (inside) {
+      const unsigned long long bb = wl.best[lane];
+      const float best = __uint_as_float((uint32_t)(bb >> 32)), second = __uint_as_float(wl.second[lane]);
+      bpos = (uint32_t)bb;
+      const bool near_tie = (second - best) <= 2.0f * err;  // inf - inf = NaN -> false
+      const bool near_thr = fabsf(best - thrf) <= err + 1e-6f * thrf;
+      if (too_long || (best <= thrf + err && (near_tie || near_thr))) verdict = O3D_CORR_PENDING;
+      else if (best < thrf) verdict = O3D_CORR_CANDIDATE;
+      if (verdict != O3D_CORR_PENDING) {
+        // decided in fp32.  Every other point (every point, without a match) is farther than: the runner-up of the scan
+        // (the winner itself without a match), the reach the unscanned cells lie beyond, the edge of the 3x3x3 block
+        const float other = (verdict == O3D_CORR_CANDIDATE ? second : best) - err;
+        const float lb2 = fminf(fminf(other, reach), capsq) * (1.0f - 1e-5f);
+        lbn = lb2 > 0.f ? sqrtf(lb2) * (1.0f - 1e-6f) : 0.f;
       }
+    }
+    const unsigned long long undecided = __ballot(verdict == O3D_CORR_PENDING);
+    for (unsigned long long m = undecided; m; m &= m - 1) {  // wave-uniform, rare: one undecided query at a time
+      const int srcl = __ffsll((long long)m) - 1;
+      const double qx64 = __shfl(x, srcl, O3D_WAVE), qy64 = __shfl(y, srcl, O3D_WAVE), qz64 = __shfl(z, srcl, O3D_WAVE);
+      const unsigned long long rpb = (unsigned long long)(uintptr_t)rowp;
+      const unsigned long long rq = ((unsigned long long)(uint32_t)__shfl((int)(rpb >> 32), srcl, O3D_WAVE) << 32) |
+                                    (uint32_t)__shfl((int)(uint32_t)rpb, srcl, O3D_WAVE);
+      uint32_t ep = 0;
+      const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
+      if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; }  // lbn stays 0: searched again next pass
     }
     // issue the gathers for this trip's candidates; they are consumed in the next trip (or after the loop)
     use_p = verdict == O3D_CORR_CANDIDATE;
-    cert_p = certified;
     i_p = i;
     xs = x; ys = y; zs = z;
-    if (use_p && !certified) {
+    if (use_p) {
       p_p = a.tgt[bpos];
       if (EST != O3D_EST_POINT_TO_POINT) {
         n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
@@ -974,8 +1056,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[bpos]; is_p = a.sint[i]; }
     }
     if (a.stats) {
-      const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid)), ncert = __popcll(__ballot(certified));
-      unsigned long long rsum = (unsigned long long)nruns, isum = tot + centre_items;
+      const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid));
+      unsigned long long rsum = (unsigned long long)nruns, isum = tot + ((s2 - s1 + 3u) >> 2);
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
         rsum += __shfl_xor(rsum, d, O3D_WAVE);
@@ -988,19 +1070,19 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
         atomicAdd(&a.ctr[3], np);
         atomicAdd(&a.ctr[4], isum);
         atomicAdd(&a.ctr[5], nv);
-        atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
       }
     }
     if (valid) {
       if (!use_p) a.corr[i] = verdict;  // a candidate's entry is written when it is confirmed
-      if (!certified) a.pos[i] = use_p ? bpos : O3D_POS_NONE;  // a certified query keeps its (unchanged) previous match
-      if (a.cert) a.lb[i] = lbn;
+      a.pos[i] = use_p ? bpos : O3D_POS_NONE;
+      a.lb[i] = lbn;
     }
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
-  if (beg < end) consume();
+  }
+  if (!first) consume();
   __syncthreads();
-  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, chunk);
+  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -1319,6 +1401,24 @@ __device__ __forceinline__ void write_log_row(const IcpState *st, const double *
   log[(size_t)pass * O3D_LOG_STRIDE + e] = v;
 }
 
+// How far the pending update moves a point of the cloud at most (points within `radius` of `centre`): when that exceeds
+// what the certificates' slack can absorb, the next pass does not try them (a prediction for speed only -- a certificate
+// that is tried is checked point by point against the distance the point really moved).
+__device__ __forceinline__ int update_skips_certificates(const IcpState *st, const double *upd) {
+  double f2 = 0.0, c[3];
+  for (int r = 0; r < 3; r++) {
+    double v = TM(upd, r, 3) - st->centre[r];
+    for (int k = 0; k < 3; k++) {
+      const double e = TM(upd, r, k) - (r == k ? 1.0 : 0.0);
+      f2 += e * e;
+      v += TM(upd, r, k) * st->centre[k];
+    }
+    c[r] = v;
+  }
+  const double moved = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + sqrt(f2) * st->radius;
+  return !(moved <= st->cert_skip_above);  // NaN: skip
+}
+
 __device__ __forceinline__ void solve_body(IcpState *__restrict__ st, const double *q, int has_normals, double *__restrict__ log, int log_rows) {
   const double nc = q[O3D_SUM_NC];
   double fit = 0.0, rmse = 0.0;
@@ -1356,6 +1456,7 @@ __device__ __forceinline__ void solve_body(IcpState *__restrict__ st, const doub
   for (int i = 0; i < 16; i++) st->update[i] = upd[i];
   mat4_mul(upd, st->T, st->T);
   st->apply_update = 1;
+  st->skip_cert = update_skips_certificates(st, upd);
 }
 
 // The loop state is staged in LDS for the one lane that runs the estimate (dozens of dependent global accesses otherwise)
@@ -1652,6 +1753,7 @@ __global__ void k_icp_set_update(IcpState *__restrict__ st, Mat16 u) {
   for (int i = 0; i < 16; i++) st->update[i] = u.m[i];
   mat4_mul(u.m, st->T, st->T);
   st->apply_update = 1;
+  st->skip_cert = update_skips_certificates(st, u.m);
   st->iters = st->iters + 1;
 }
 
@@ -1810,10 +1912,8 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
   pa.seed = ctx->use_seed;
-  // the bounds refer to the position of the previous pass: not in hypothesis mode, where every pass starts from the original
-  pa.cert = (ctx->use_cert && !ctx->hyp_mode) ? 1 : 0;
-  pa.gap = (float)(ctx->cert_gap * ctx->gp.h);
   pa.lb = ctx->lb_sorted;
+  pa.work = ctx->work; pa.work_count = ctx->work_count;
   pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
   const int est = ctx->estimation;
 #define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \
@@ -1830,7 +1930,33 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   // o3d_debug_set): the per-lane fp64 search followed by the accumulation kernel.  One partial row per workgroup.
   const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
   const int grows = fused ? ctx->search_grid : ctx->pass_grid;
-  const int nparts = grows;
+  int nparts = grows;
+  // Certificates: the bounds refer to the position of the previous pass -- not in hypothesis mode, where every pass starts
+  // from the untouched source, and not in the first pass, which has nothing to certify.  The work list is laid out for the
+  // search kernel's chunks, so k_icp_cert runs on the same grid.
+  const bool cert = fused && ctx->use_cert && !ctx->hyp_mode;
+  pa.gap = cert ? (float)(ctx->cert_gap * ctx->gp.h) : 0.f;
+  pa.listed = (cert && ctx->enq_passes > 1) ? 1 : 0;  // enq_passes counts this pass already
+  pa.cert_row0 = grows;
+  {  // common segments: 4 wavefronts x grid x segments per wavefront is the same number for both kernels
+    const int cg = fused ? ctx->cert_grid : grows;
+    int ma = 1, mb = 1;
+    if (cg != grows) {
+      int x = cg, y = grows;
+      while (y) { const int t = x % y; x = y; y = t; }  // x = gcd
+      ma = grows / x;
+      mb = cg / x;
+    }
+    const int64_t nseg = 4 * (int64_t)grows * mb;
+    pa.segs_per_wave = mb;
+    pa.segs_per_wave_cert = ma;
+    pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
+    if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
+  }
+  if (pa.listed) {
+    O3D_LAUNCH_EST(k_icp_cert, ctx->cert_grid, pa);
+    nparts = grows + ctx->cert_grid;
+  }
   if (fused) {
     O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));

@@ -45,6 +45,8 @@ struct IcpState {
   double rel_fitness, rel_rmse;
   double centre[3];   // fixed origin subtracted inside the Umeyama sums
   double n_src_global;
+  double radius;            // half diagonal of the target's bounding box about `centre`
+  double cert_skip_above;   // a pending update that moves the cloud farther than this makes k_icp_cert stand aside
   int max_iter;
   int passes;        // LOOP-A passes completed
   int iters;         // estimation updates applied
@@ -52,7 +54,7 @@ struct IcpState {
   int apply_update;  // next pass transforms the source by `update`
   int estimation;
   int with_scaling;
-  int pad;
+  int skip_cert;     // the pending update is too large for the certificates (k_icp_cert returns at once, everything is searched)
 };
 
 struct o3d_ctx {
@@ -84,6 +86,9 @@ struct o3d_ctx {
   int32_t *corr_out = nullptr;     // caller's order (device staging)
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
   float *lb_sorted = nullptr;      // per processing position: lower bound on the distance to every OTHER target point
+  uint32_t *work = nullptr;        // work list of the search kernel (k_icp_cert), one segment per wavefront
+  uint32_t *work_count = nullptr;  // O3D_MAX_GRID * 4 counters
+  int cert_grid = 0;               // workgroups of k_icp_cert
   size_t cap_src = 0;
   double *src_orig = nullptr;      // hypothesis mode: the source in processing order, never transformed
   size_t cap_src_orig = 0;
