@@ -451,15 +451,6 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
   }
   ctx->search_grid = (int)gs;
-  // k_icp_cert runs on the same grid by default (its pass is bound by memory traffic, not by occupancy: 1536 and 2048
-  // workgroups measured 7 % and 5 % slower).  The two kernels walk the same segments of the source (o3d_launch_pass), so
-  // other grids stay possible: O3D_CERT_GRID = 1536 or 2048, tuning aid.
-  int64_t gc = gs;
-  if (const char *e = getenv("O3D_CERT_GRID")) {
-    const long v = atol(e);
-    if (gs == O3D_NUM_CU * 4 && (v == 1536 || v == 2048) && g >= v) gc = v;
-  }
-  ctx->cert_grid = (int)gc;
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
   ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : 1;  // tuning aid
   if (const char *e = getenv("O3D_CERT_GAP")) {

@@ -290,8 +290,6 @@ struct PassArgs {
   uint32_t *work;        // work list: per wavefront, from the start of its range, the positions k_icp_cert could not certify
   uint32_t *work_count;  // per segment
   int64_t seg_len;       // positions per segment (a multiple of 64)
-  int segs_per_wave;     // k_icp_search_coop: segments per wavefront
-  int segs_per_wave_cert;  // k_icp_cert: segments per wavefront (the two grids differ, the segments are common)
   int cert_row0;   // first partial row of k_icp_cert (the rows of k_icp_search_coop come first)
   double *partials;
   double thr;
@@ -738,22 +736,19 @@ __device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tg
 // cloud) turns the first launch into a no-op when the bounds cannot hold anyway; the search then runs over everything,
 // as it does in the first pass.
 
-// The wavefront's share of the source.  The source is cut into segments of PassArgs::seg_len positions (a multiple of 64);
-// wavefront `wave` of the workgroup that owns chunk c -- workgroup -> chunk is XCD-aware, see k_icp_search -- takes the
-// `m` consecutive segments from slot * m on, slot = c * 4 + wave.  k_icp_cert runs with m = 1 on a grid m' times that of
-// k_icp_search_coop, which takes m' segments per wavefront: both walk the same segments, the work list and its counters
-// are per segment.
+// The wavefront's share of the source: one segment of PassArgs::seg_len positions (a multiple of 64), segment number =
+// chunk * 4 + wavefront, workgroup -> chunk XCD-aware (see k_icp_search).  k_icp_cert and k_icp_search_coop run on the same
+// grid and walk the same segments; the work list and its counters are per segment.
 struct WaveRange {
-  unsigned chunk;
-  unsigned seg0;     // first segment
-  int64_t beg, end;  // positions [beg, end) of all m segments
+  unsigned chunk, seg;
+  int64_t beg, end;
 };
-__device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, int m) {
+__device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len) {
   WaveRange r;
   r.chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  r.seg0 = (r.chunk * 4u + (threadIdx.x >> 6)) * (unsigned)m;
-  r.beg = (int64_t)r.seg0 * seg_len;
-  r.end = r.beg + (int64_t)m * seg_len;
+  r.seg = r.chunk * 4u + (threadIdx.x >> 6);
+  r.beg = (int64_t)r.seg * seg_len;
+  r.end = r.beg + seg_len;
   if (r.end > n_src) r.end = n_src;
   if (r.beg > r.end) r.beg = r.end;
   return r;
@@ -765,7 +760,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
   static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
   const int tid = threadIdx.x, lane = tid & 63;
-  const WaveRange wr = wave_range(a.n_src, a.seg_len, a.segs_per_wave_cert);
+  const WaveRange wr = wave_range(a.n_src, a.seg_len);
   if (a.st->skip_cert) {  // the pending update moves the cloud farther than any bound reaches: everything is searched
     if (tid < O3D_NSUMS) a.partials[((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid] = 0.0;
     return;
@@ -778,13 +773,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
   const float thrf = (float)a.thr;
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
   unsigned long long ncert = 0;
-  for (int sg = 0; sg < a.segs_per_wave_cert; sg++) {
-  const int64_t sbeg = wr.beg + (int64_t)sg * a.seg_len;
-  const int64_t send = sbeg + a.seg_len < wr.end ? sbeg + a.seg_len : wr.end;
   uint32_t nwork = 0;  // wave-uniform
-  for (int64_t base = sbeg; base < send; base += O3D_WAVE) {
+  for (int64_t base = wr.beg; base < wr.end; base += O3D_WAVE) {
     const int64_t i = base + lane;
-    const bool valid = i < send;
+    const bool valid = i < wr.end;
     double x = 0, y = 0, z = 0;
     uint32_t pprev = O3D_POS_NONE;
     float lbv = 0.f, moved = 0.f;
@@ -832,14 +824,15 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
       a.lb[i] = lbc;
     }
     const unsigned long long need = __ballot(valid && !certified);
-    if (valid && !certified) a.work[sbeg + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    if (valid && !certified) a.work[wr.beg + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
     nwork += (uint32_t)__popcll(need);
     if (a.stats) ncert += __popcll(__ballot(certified));
     push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
   }
-  if (lane == 0) a.work_count[wr.seg0 + sg] = nwork;
+  if (lane == 0) {
+    a.work_count[wr.seg] = nwork;
+    if (a.stats && ncert) atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
   }
-  if (lane == 0 && a.stats && ncert) atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
   __syncthreads();  // every wavefront is done with its staging buffer
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
 }
@@ -861,8 +854,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   const int apply = listed ? 0 : a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-  const int nseg = listed ? a.segs_per_wave : 1;  // listed: one work-list segment after the other; else the whole range at once
-  const WaveRange wr = wave_range(a.n_src, a.seg_len, a.segs_per_wave);
+  const WaveRange wr = wave_range(a.n_src, a.seg_len);
+  const int64_t nq = listed ? (int64_t)a.work_count[wr.seg] : wr.end - wr.beg;  // wave-uniform
   const float hf = (float)gp.h;
   const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
@@ -905,13 +898,9 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     push_sums<EST>(wl.vb, lane, S, use_p, xs, ys, zs, p_p, n0_p, n1_p, n2_p, d2, cx0, cy0, cz0, tc_p, is_p, a.slg, a.slp);
   };
 
-  bool first = true;
-  for (int sg = 0; sg < nseg; sg++) {
-  const int64_t sbeg = wr.beg + (int64_t)sg * a.seg_len;
-  const int64_t nq = listed ? (sbeg < wr.end ? (int64_t)a.work_count[wr.seg0 + sg] : 0) : wr.end - wr.beg;  // wave-uniform
   for (int64_t k0 = 0; k0 < nq; k0 += O3D_WAVE) {  // wave-uniform trip count
     const bool valid = k0 + lane < nq;
-    int64_t i = sbeg + k0 + lane;
+    int64_t i = wr.beg + k0 + lane;
     if (listed && valid) i = a.work[i];
     double x = 0, y = 0, z = 0;
     uint32_t pprev = O3D_POS_NONE;
@@ -946,8 +935,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     const bool has_seed = inside && pprev != O3D_POS_NONE;
     double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
     if (has_seed) ps = a.tgt[pprev];
-    if (!first) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
-    first = false;
+    if (k0 != 0) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
     bool too_long = s3 - s0 >= kRunMaxLen;
     float seedb = INFINITY;
     if (has_seed) {
@@ -1079,8 +1067,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     }
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
   }
-  }
-  if (!first) consume();
+  if (nq > 0) consume();
   __syncthreads();
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
 }
@@ -1938,24 +1925,14 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.gap = cert ? (float)(ctx->cert_gap * ctx->gp.h) : 0.f;
   pa.listed = (cert && ctx->enq_passes > 1) ? 1 : 0;  // enq_passes counts this pass already
   pa.cert_row0 = grows;
-  {  // common segments: 4 wavefronts x grid x segments per wavefront is the same number for both kernels
-    const int cg = fused ? ctx->cert_grid : grows;
-    int ma = 1, mb = 1;
-    if (cg != grows) {
-      int x = cg, y = grows;
-      while (y) { const int t = x % y; x = y; y = t; }  // x = gcd
-      ma = grows / x;
-      mb = cg / x;
-    }
-    const int64_t nseg = 4 * (int64_t)grows * mb;
-    pa.segs_per_wave = mb;
-    pa.segs_per_wave_cert = ma;
+  {  // one segment per wavefront, the same for both kernels
+    const int64_t nseg = 4 * (int64_t)grows;
     pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
     if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
   }
   if (pa.listed) {
-    O3D_LAUNCH_EST(k_icp_cert, ctx->cert_grid, pa);
-    nparts = grows + ctx->cert_grid;
+    O3D_LAUNCH_EST(k_icp_cert, grows, pa);
+    nparts = 2 * grows;
   }
   if (fused) {
     O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);

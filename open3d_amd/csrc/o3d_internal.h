@@ -87,8 +87,7 @@ struct o3d_ctx {
   uint32_t *pos_sorted = nullptr;  // per processing position: position of the match in tgt_sorted
   float *lb_sorted = nullptr;      // per processing position: lower bound on the distance to every OTHER target point
   uint32_t *work = nullptr;        // work list of the search kernel (k_icp_cert), one segment per wavefront
-  uint32_t *work_count = nullptr;  // O3D_MAX_GRID * 4 counters
-  int cert_grid = 0;               // workgroups of k_icp_cert
+  uint32_t *work_count = nullptr;  // one counter per segment (4 per workgroup)
   size_t cap_src = 0;
   double *src_orig = nullptr;      // hypothesis mode: the source in processing order, never transformed
   size_t cap_src_orig = 0;
@@ -110,7 +109,7 @@ struct o3d_ctx {
   int search_grid = 0;  // workgroups of k_icp_search_coop
   int use_seed = 1;     // k_icp_search_coop: previous match as the first pruning bound (O3D_NO_SEED=1 turns it off)
   int use_cert = 1;     // k_icp_search_coop: certified previous matches skip the search (O3D_NO_CERT=1 turns it off)
-  double cert_gap = 0.125;  // extra search reach for the certificates' slack, in cells (O3D_CERT_GAP)
+  double cert_gap = 0.0625;  // extra search reach for the certificates' slack, in cells (O3D_CERT_GAP)
   int icp_ready = 0;
   int max_iter = 0;
   int enq_passes = 0;
