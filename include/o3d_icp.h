@@ -217,8 +217,9 @@ O3D_API int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *o
  * of the pass kernel(s) over the recorded passes and their number, and clears the record. */
 O3D_API int o3d_icp_profile(o3d_ctx *ctx, int enable);
 O3D_API int o3d_icp_profile_read(o3d_ctx *ctx, double *out_mean_ms, int *out_count);
-/* Same, split: out_mean_ms[0] = k_icp_search_coop (the one kernel of a pass; k_icp_search on the alternative path),
- * [1] = k_icp_accumulate_mfma (alternative path only; otherwise ~0). */
+/* Same, split into the two kernels of a pass: out_mean_ms[0] = k_icp_cert (certified previous matches; absent, ~0, in the
+ * first pass and without certificates), [1] = k_icp_search_coop (the search over what is left).  On the alternative
+ * path: [0] = k_icp_search, [1] = k_icp_accumulate_mfma. */
 O3D_API int o3d_icp_profile_read2(o3d_ctx *ctx, double out_mean_ms[2], int *out_count);
 /* Same record, pass by pass (search + accumulation kernels of each recorded pass, milliseconds); does not clear it. */
 O3D_API int o3d_icp_profile_read_all(o3d_ctx *ctx, double *out_ms, int max_count, int *out_count);

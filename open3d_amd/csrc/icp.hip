@@ -1934,9 +1934,9 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     O3D_LAUNCH_EST(k_icp_cert, grows, pa);
     nparts = 2 * grows;
   }
-  if (fused) {
-    O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
+  if (fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
+    O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
   } else {
     hipLaunchKernelGGL(k_icp_search, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));

@@ -81,12 +81,13 @@ def test_surface_1m_matches_kdtree_oracle(ctx, oracle):
     _check(ctx, oracle, sc["source"], sc["target"], 2 * sc["spacing"])
 
 
-def test_headline_size_10m_properties(ctx, oracle):
-    """BASELINE headline size (10 M x 10 M, point-to-plane): the oracle is too slow for a full run, so the full-size run is
-    checked through size-independent properties -- (1) on a 100 k sample of source points the correspondences equal the
-    oracle's KD-tree search over the full 10 M target, bit for bit; (2) permuting the source permutes the result and leaves
-    fitness / rmse / transformation unchanged (the Hilbert processing order and the fixed-order reductions are internal);
-    (3) every reported match is inside the radius and the summary numbers follow from the correspondence array."""
+def test_headline_size_10m_every_point(ctx, oracle):
+    """BASELINE headline size (10 M x 10 M, point-to-plane, 3 iterations): ALL of it against the oracle -- the KD-tree
+    restatement does its four passes over the 10 M points in a few seconds on the box's cores.  (1) every pass's
+    correspondence count identical, fitness / rmse / transformation within 1e-6; the final correspondence array bit-exact
+    on all 10 M points.  (2) Permuting the source permutes the result and leaves fitness / rmse / transformation unchanged
+    (the Hilbert processing order and the fixed-order reductions are internal).  (3) The summary numbers follow from the
+    correspondence array.  (4) A fresh EvaluateRegistration at the result equals the loop's last search."""
     from open3d_amd import geometry, synthetic
     from open3d_amd.pipelines import registration as reg
     n = 10_000_000
@@ -98,8 +99,23 @@ def test_headline_size_10m_properties(ctx, oracle):
     crit = reg.ICPConvergenceCriteria(0.0, 0.0, 3)
     est = reg.TransformationEstimationPointToPlane()
     target = geometry.PointCloud(tgt, normals=nrm)
-    got = reg.RegistrationICP(geometry.PointCloud(src), target, r, np.eye(4), est, crit, ctx=ctx)
+    sess = reg.IcpSession(ctx).setup(src, tgt, nrm, r, np.eye(4), est, crit)
+    sess.run()
+    got = sess.finish()
+    log = sess.log()
     assert got.iterations_ == 3 and got.fitness_ > 0.99
+
+    # (1) the whole run against the oracle
+    ref = oracle.registration_icp(src, tgt, r, None, 2, nrm, rel_fitness=0.0, rel_rmse=0.0, max_iter=3, want_log=True)
+    assert ref.iterations == 3 and len(log) == len(ref.log) == 4
+    for p in range(4):
+        assert log[p, 2] == ref.log[p, 2], "n_corr differs at pass %d" % p
+        assert rel_err(log[p, 0], ref.log[p, 0]) < 1e-6 and rel_err(log[p, 1], ref.log[p, 1]) < 1e-6
+        assert rel_err(log[p, 4:20], ref.log[p, 4:20]) < 1e-6
+    bad = np.nonzero(got.corr_ != ref.corr)[0]
+    assert len(bad) == 0, "%d of %d correspondences differ, first at %s" % (len(bad), n, bad[:5])
+    assert rel_err(got.transformation_, ref.transformation) < 1e-6
+    assert rel_err(got.fitness_, ref.fitness) < 1e-6 and rel_err(got.inlier_rmse_, ref.inlier_rmse) < 1e-6
 
     # (3) consistency of the summary with the correspondences
     m = got.corr_ >= 0
@@ -110,20 +126,50 @@ def test_headline_size_10m_properties(ctx, oracle):
     assert got.fitness_ == m.sum() / n
     assert abs(got.inlier_rmse_ - np.sqrt(d2.mean())) < 1e-9 * got.inlier_rmse_
 
-    # (1) sample against the KD-tree oracle over the full target, under the final transformation
-    rng = np.random.default_rng(0)
-    pick = np.sort(rng.choice(n, 100_000, replace=False))
+    # (4) the loop's last search == a fresh evaluation at its result
     ev = reg.EvaluateRegistration(geometry.PointCloud(src), geometry.PointCloud(tgt), r, T, ctx=ctx)
-    assert np.array_equal(ev.corr_, got.corr_)          # the loop's last search == a fresh evaluation at its result
-    ref_corr = oracle.evaluate_registration(src[pick], tgt, r, T)[0]
-    assert np.array_equal(ev.corr_[pick], ref_corr)
+    assert np.array_equal(ev.corr_, got.corr_)
 
     # (2) permutation of the source
+    rng = np.random.default_rng(0)
     perm = rng.permutation(n)
     got_p = reg.RegistrationICP(geometry.PointCloud(src[perm]), target, r, np.eye(4), est, crit, ctx=ctx)
     assert np.array_equal(got_p.corr_, got.corr_[perm])
     assert got_p.fitness_ == got.fitness_
     assert np.abs(got_p.transformation_ - T).max() < 1e-12 and abs(got_p.inlier_rmse_ - got.inlier_rmse_) < 1e-15
+
+
+def test_config2_full_size_end_to_end(ctx, oracle):
+    """BASELINE config 2 at full size: 1 M x 1 M, EstimateNormals(Hybrid(4 spacings, 30)) on the GPU, point-to-plane ICP with
+    the default criteria.  (a) the GPU's normals against the oracle's (1e-9; the closed form's sign is the same on both
+    sides); (b) the strict check: the oracle's ICP fed with THE GPU'S normals must give the GPU's correspondences bit for
+    bit, the same number of iterations and T / fitness / rmse within 1e-6; (c) the two chains end to end (each with its own
+    normals, which differ in the last digits): same iteration count, T within 1e-6, correspondences equal except where a
+    1e-9 change of the pose flips a near-tie -- at most a handful of the million."""
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    sc = make_scene(1_000_000, 1_000_000, cfg_id=2, L=6.32)
+    s = sc["spacing"]
+    r = 2 * s
+    pc = geometry.PointCloud(sc["target"])
+    pc.EstimateNormals(geometry.KDTreeSearchParamHybrid(4.0 * s, 30), ctx=ctx)
+    gpu_n = pc.normals_
+    ref_n = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    assert np.abs(gpu_n - ref_n).max() < 1e-9                                                   # (a)
+    est = reg.TransformationEstimationPointToPlane()
+    got = reg.RegistrationICP(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=gpu_n), r, np.eye(4), est,
+                              reg.ICPConvergenceCriteria(), ctx=ctx)
+    ref = oracle.registration_icp(sc["source"], sc["target"], r, None, 2, gpu_n)                 # (b)
+    assert got.iterations_ == ref.iterations
+    bad = np.nonzero(got.corr_ != ref.corr)[0]
+    assert len(bad) == 0, "%d correspondences differ, first at %s" % (len(bad), bad[:5])
+    assert rel_err(got.transformation_, ref.transformation) < 1e-6
+    assert rel_err(got.fitness_, ref.fitness) < 1e-6 and rel_err(got.inlier_rmse_, ref.inlier_rmse) < 1e-6
+    assert rel_err(got.transformation_, sc["T_true"]) < 1e-3      # and it is the pose the scene was built with
+    chain = oracle.registration_icp(sc["source"], sc["target"], r, None, 2, ref_n)               # (c)
+    assert chain.iterations == got.iterations_
+    assert rel_err(got.transformation_, chain.transformation) < 1e-6
+    assert np.count_nonzero(got.corr_ != chain.corr) <= 8
 
 
 @pytest.mark.gpu
