@@ -65,6 +65,18 @@ typedef enum { O3D_SEARCH_KNN = 0, O3D_SEARCH_RADIUS = 1, O3D_SEARCH_HYBRID = 2 
 
 /* ---- context -------------------------------------------------------------- */
 O3D_API int o3d_ctx_create(int device_id, o3d_ctx **out_ctx);
+/* One context over several GPUs of the node (no reference counterpart: the reference is single-process CPU code; SURVEY.md
+ * 8e).  The context is rank 0 (device_ids[0]) and behaves like an ordinary context in every entry point; in addition
+ * o3d_registration_icp -- and with it the C++ RegistrationICP of the adapter -- splits the source into n_devices contiguous
+ * shards, builds the target grid on every device and exchanges 32 fp64 sums per rank and iteration through pinned host
+ * memory, every rank adding the table in rank order: the same transformation on every rank, the correspondence array the
+ * concatenation of the shards.  The same device may be listed more than once (a rehearsal of the sharded path on one GPU).
+ * o3d_estimate_normals splits its per-point loop the same way (every device builds the grid, computes the normals of its
+ * range of the cell-ordered cloud, device 0 assembles them: bit-identical to the one-device call).
+ * With mem = O3D_MEM_DEVICE the caller's buffers must be readable from every listed device (peer access is enabled here
+ * where the hardware offers it).  n_devices = 1 is o3d_ctx_create. */
+O3D_API int o3d_ctx_create_multi(int n_devices, const int *device_ids, o3d_ctx **out_ctx);
+O3D_API int o3d_ctx_num_devices(const o3d_ctx *ctx);
 O3D_API void o3d_ctx_destroy(o3d_ctx *ctx);
 /* Launch everything on an existing hipStream_t (e.g. torch's current stream).  The handle is used as given: NULL is
  * the HIP null stream (torch's default stream), so that work enqueued by the caller on that stream -- an RCCL

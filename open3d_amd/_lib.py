@@ -22,6 +22,8 @@ c_ip = C.POINTER(C.c_int32)
 
 _SIGNATURES = {
     "o3d_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "o3d_ctx_create_multi": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "o3d_ctx_num_devices": (C.c_int, [C.c_void_p]),
     "o3d_ctx_destroy": (None, [C.c_void_p]),
     "o3d_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_ctx_use_own_stream": (C.c_int, [C.c_void_p]),
@@ -159,11 +161,20 @@ class Context:
     """One GPU + one stream + scratch memory (o3d_ctx)."""
 
     def __init__(self, device=0):
+        """device: one device id, or a sequence of ids for a context over several GPUs (o3d_ctx_create_multi: RegistrationICP
+        then shards the source over them; the same id may repeat to rehearse the sharded path on one GPU)."""
         self._lib = load()
         h = C.c_void_p()
-        st = self._lib.o3d_ctx_create(int(device), C.byref(h))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            st = self._lib.o3d_ctx_create_multi(len(device), ids, C.byref(h))
+            self.devices = [int(d) for d in device]
+            device = self.devices[0]
+        else:
+            st = self._lib.o3d_ctx_create(int(device), C.byref(h))
+            self.devices = [int(device)]
         if st != STATUS_OK:
-            raise O3DError(st, "o3d_ctx_create(%d) failed: %s" % (device, self._lib.o3d_last_error(None).decode()))
+            raise O3DError(st, "o3d_ctx_create(%s) failed: %s" % (self.devices, self._lib.o3d_last_error(None).decode()))
         self._h = h
         self.device = device
 

@@ -17,6 +17,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -40,14 +41,32 @@ class Context {
     const int st = o3d_ctx_create(device, &ctx_);
     if (st != O3D_OK) throw std::runtime_error(std::string("open3d_amd: ") + o3d_last_error(nullptr));
   }
+  // One context over several GPUs of the node (o3d_ctx_create_multi): RegistrationICP shards its source over them.
+  explicit Context(const std::vector<int> &devices) {
+    const int st = o3d_ctx_create_multi((int)devices.size(), devices.data(), &ctx_);
+    if (st != O3D_OK) throw std::runtime_error(std::string("open3d_amd: ") + o3d_last_error(nullptr));
+  }
   ~Context() { o3d_ctx_destroy(ctx_); }
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
   o3d_ctx *get() const { return ctx_; }
-  // One context per host thread and device; created on first use.
+  // One context per host thread; created on first use.  O3D_AMD_DEVICES="0,1,2,3" in the environment makes it span those
+  // GPUs, so that an unchanged caller of RegistrationICP(source, target, ...) uses all of them.
   static Context &Default(int device = 0) {
     thread_local std::unique_ptr<Context> c;
-    if (!c) c.reset(new Context(device));
+    if (!c) {
+      std::vector<int> ids;
+      if (const char *e = std::getenv("O3D_AMD_DEVICES")) {
+        int v = 0;
+        bool have = false;
+        for (const char *p = e;; p++) {
+          if (*p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); have = true; }
+          else { if (have) ids.push_back(v); v = 0; have = false; if (!*p) break; }
+        }
+      }
+      if (ids.size() > 1) c.reset(new Context(ids));
+      else c.reset(new Context(ids.empty() ? device : ids[0]));
+    }
     return *c;
   }
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <random>
@@ -226,6 +227,11 @@ struct o3d_ctx_full : o3d_ctx {
   std::recursive_mutex mu;  // one call in flight per context: concurrent callers of the same context are serialised
   o3d_staging stage;
   std::vector<o3d_ctx *> workers;  // contexts of the batch worker threads (created on first use, kept)
+  // o3d_ctx_create_multi: this context is rank 0 of `ranks` (ranks[0] == this); empty for an ordinary context
+  std::vector<o3d_ctx *> ranks;
+  double *mailbox = nullptr;            // pinned host memory mapped into every device: [parity][rank][32 sums]
+  std::vector<double *> mailbox_dev;    // the same memory as each rank's device sees it
+  std::vector<hipEvent_t> xev;          // [parity * G + rank]: the rank's sums of this parity are in the mailbox
 };
 static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
 #define O3D_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock__(static_cast<o3d_ctx_full *>(ctx)->mu)
@@ -299,11 +305,78 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   return O3D_OK;
 }
 
+int o3d_ctx_create_multi(int n_devices, const int *device_ids, o3d_ctx **out_ctx) {
+  if (!out_ctx) return O3D_ERR_INVALID_ARG;
+  *out_ctx = nullptr;
+  if (n_devices < 1 || n_devices > 64 || !device_ids) return o3d_fail(nullptr, O3D_ERR_INVALID_ARG, "o3d_ctx_create_multi: 1..64 devices");
+  o3d_ctx *first = nullptr;
+  O3D_TRY(o3d_ctx_create(device_ids[0], &first));
+  if (n_devices == 1) { *out_ctx = first; return O3D_OK; }
+  o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(first);
+  const int G = n_devices;
+  auto bail = [&](int st, const char *what, hipError_t e) {
+    o3d_fail(nullptr, st, "o3d_ctx_create_multi: %s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    o3d_ctx_destroy(ctx);
+    return st;
+  };
+  ctx->ranks.push_back(ctx);
+  for (int r = 1; r < G; r++) {
+    o3d_ctx *c = nullptr;
+    const int st = o3d_ctx_create(device_ids[r], &c);
+    if (st != O3D_OK) { o3d_ctx_destroy(ctx); return st; }  // the message of o3d_ctx_create stands
+    ctx->ranks.push_back(c);
+  }
+  // caller buffers in device memory live on one GPU and are read by the kernels of all of them
+  for (int a = 0; a < G; a++)
+    for (int b = 0; b < G; b++) {
+      const int da = device_ids[a], db = device_ids[b];
+      if (da == db) continue;
+      DeviceGuard g(da);
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) { (void)hipGetLastError(); continue; }  // host buffers still work
+      const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(O3D_ERR_HIP, "hipDeviceEnablePeerAccess", e);
+      (void)hipGetLastError();
+    }
+  hipError_t e = hipHostMalloc((void **)&ctx->mailbox, sizeof(double) * 2 * (size_t)G * O3D_NSUMS, hipHostMallocPortable | hipHostMallocMapped);
+  if (e != hipSuccess) return bail(O3D_ERR_HIP, "hipHostMalloc(mailbox)", e);
+  memset(ctx->mailbox, 0, sizeof(double) * 2 * (size_t)G * O3D_NSUMS);
+  ctx->mailbox_dev.assign((size_t)G, nullptr);
+  ctx->xev.assign(2 * (size_t)G, nullptr);
+  for (int r = 0; r < G; r++) {
+    DeviceGuard g(device_ids[r]);
+    void *dp = nullptr;
+    if ((e = hipHostGetDevicePointer(&dp, ctx->mailbox, 0)) != hipSuccess) return bail(O3D_ERR_HIP, "hipHostGetDevicePointer(mailbox)", e);
+    ctx->mailbox_dev[(size_t)r] = static_cast<double *>(dp);
+    for (int par = 0; par < 2; par++)
+      if ((e = hipEventCreateWithFlags(&ctx->xev[(size_t)(par * G + r)], hipEventDisableTiming)) != hipSuccess)
+        return bail(O3D_ERR_HIP, "hipEventCreate", e);
+  }
+  *out_ctx = ctx;
+  return O3D_OK;
+}
+
+int o3d_ctx_num_devices(const o3d_ctx *c) {
+  if (!c) return 0;
+  const o3d_ctx_full *ctx = static_cast<const o3d_ctx_full *>(c);
+  return ctx->ranks.empty() ? 1 : (int)ctx->ranks.size();
+}
+
 void o3d_ctx_destroy(o3d_ctx *c) {
   if (!c) return;
   o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(c);
   for (o3d_ctx *w : ctx->workers) o3d_ctx_destroy(w);
   ctx->workers.clear();
+  for (size_t k = 0; k < ctx->xev.size(); k++)
+    if (ctx->xev[k]) {
+      DeviceGuard g(ctx->ranks[k % ctx->ranks.size()]->device);
+      (void)hipEventDestroy(ctx->xev[k]);
+    }
+  ctx->xev.clear();
+  for (size_t r = 1; r < ctx->ranks.size(); r++) o3d_ctx_destroy(ctx->ranks[r]);
+  ctx->ranks.clear();
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  ctx->mailbox = nullptr;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
@@ -740,12 +813,118 @@ static int run_icp_loop(o3d_ctx *ctx, int max_iter) {
   return O3D_OK;
 }
 
+// RegistrationICP over the G devices of a multi context: contiguous shards of the source, the target grid built
+// on every device, one exchange of 32 sums per rank and iteration through a pinned host mailbox that every device maps.
+// One host thread per rank enqueues, per iteration,
+//     pass (k_icp_cert, k_icp_search_coop) -> k_icp_finalize into mailbox[parity][rank] -> event
+//     wait for the other ranks' events -> k_icp_solve over mailbox[parity][0..G) in rank order
+// so the device never waits for the host and every rank computes bit-identical transformations from the same table; the
+// threads meet at a host barrier between "record" and "wait" (an event must have been recorded before another stream is
+// told to wait for it).  Two mailbox parities suffice: a rank rewrites a slot two iterations later, behind its own solve
+// of the iteration in between, which has waited for every rank's sums of that iteration -- each enqueued behind that
+// rank's read of the slot.
+namespace {
+// The rank threads meet once per iteration, a few microseconds apart: spin (a futex wake-up costs more than the iteration
+// of a small shard), yield when the wait drags on.
+struct HostBarrier {
+  const int n;
+  std::atomic<int> waiting{0};
+  std::atomic<unsigned> gen{0};
+  explicit HostBarrier(int n_) : n(n_) {}
+  void wait() {
+    const unsigned g = gen.load(std::memory_order_acquire);
+    if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      waiting.store(0, std::memory_order_relaxed);
+      gen.store(g + 1, std::memory_order_release);
+      return;
+    }
+    for (unsigned spins = 0; gen.load(std::memory_order_acquire) == g; spins++)
+      if (spins > 2000) std::this_thread::yield();
+  }
+};
+}  // namespace
+
+static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
+                                  int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
+                                  double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
+                                  int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+  const int G = (int)m->ranks.size();
+  if (n_src < 0 || max_iter < 0) return o3d_fail(m, O3D_ERR_INVALID_ARG, "bad sizes");
+  HostBarrier bar(G);
+  std::atomic<int> failed(0), stop(0);
+  std::vector<int> status((size_t)G, O3D_OK);
+  const bool can_break = rel_fitness > 0.0 && rel_rmse > 0.0;
+  const int kChunk = 6;
+  auto work = [&](int r) {
+    o3d_ctx *c = m->ranks[(size_t)r];
+    std::unique_lock<std::recursive_mutex> lock(static_cast<o3d_ctx_full *>(c)->mu);
+    DeviceGuard guard(c->device);
+    const int64_t lo = n_src * r / G, hi = n_src * (r + 1) / G;
+    int st = o3d_icp_setup(c, src_xyz ? src_xyz + 3 * lo : nullptr, hi - lo, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation,
+                           with_scaling, rel_fitness, rel_rmse, max_iter, mem, n_src);
+    auto sync_point = [&]() {  // every rank arrives, whatever happened to it; afterwards all agree on whether to go on
+      if (st != O3D_OK) failed.store(1);
+      bar.wait();
+      return failed.load() == 0;
+    };
+    double *box = m->mailbox_dev[(size_t)r];
+    volatile int *flag = reinterpret_cast<volatile int *>((char *)c->pinned + 3072);
+    bool pending = false;
+    if (sync_point()) {
+      if (can_break && !c->poll_ev && hipEventCreateWithFlags(&c->poll_ev, hipEventDisableTiming) != hipSuccess)
+        st = o3d_fail(c, O3D_ERR_HIP, "hipEventCreate");
+      for (int it = 0; it <= max_iter; it++) {  // passes 0 .. max_iter (Registration.cpp:154-166)
+        const int par = it & 1;
+        if (st == O3D_OK) st = o3d_icp_pass_to(c, box + ((size_t)par * G + r) * O3D_NSUMS);
+        if (st == O3D_OK && hipEventRecord(m->xev[(size_t)(par * G + r)], c->stream) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipEventRecord");
+        // rank 0 looks at the flag a chunk of iterations after it was copied (the device never waits for the host)
+        if (r == 0 && st == O3D_OK && pending && it % kChunk == 0) {
+          if (hipEventSynchronize(c->poll_ev) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipEventSynchronize");
+          else if (*flag) stop.store(1);
+          pending = false;
+        }
+        if (!sync_point() || stop.load()) break;
+        for (int q = 0; q < G && st == O3D_OK; q++)
+          if (q != r && hipStreamWaitEvent(c->stream, m->xev[(size_t)(par * G + q)], 0) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipStreamWaitEvent");
+        if (st == O3D_OK) st = o3d_icp_solve(c, box + (size_t)par * G * O3D_NSUMS, G);
+        if (r == 0 && st == O3D_OK && can_break && it % kChunk == kChunk - 1 && it < max_iter) {
+          if (hipMemcpyAsync((void *)flag, &c->state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+              hipEventRecord(c->poll_ev, c->stream) != hipSuccess)
+            st = o3d_fail(c, O3D_ERR_HIP, "flag copy");
+          pending = true;
+        }
+      }
+    }
+    // results: the transformation / fitness / rmse are the same on every rank; the correspondences are the rank's shard
+    if (st == O3D_OK && failed.load() == 0)
+      st = o3d_icp_finish(c, mem, r == 0 ? out_T : nullptr, out_corr ? out_corr + lo : nullptr, r == 0 ? out_n_corr : nullptr,
+                          r == 0 ? out_fitness : nullptr, r == 0 ? out_rmse : nullptr, r == 0 ? out_iters : nullptr);
+    else if (c->stream)
+      (void)hipStreamSynchronize(c->stream);
+    status[(size_t)r] = st;
+  };
+  std::vector<std::thread> threads;
+  for (int r = 1; r < G; r++) threads.emplace_back(work, r);
+  work(0);
+  for (auto &t : threads) t.join();
+  for (int r = 0; r < G; r++)
+    if (status[(size_t)r] != O3D_OK) {
+      if (r == 0) return status[0];  // its message is already on this context
+      return o3d_fail(m, status[(size_t)r], "rank %d (device %d): %s", r, m->ranks[(size_t)r]->device, o3d_last_error(m->ranks[(size_t)r]));
+    }
+  return O3D_OK;
+}
+
 int o3d_registration_icp(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
                          int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
                          double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
                          int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);  // held for the whole call
+  if (static_cast<o3d_ctx_full *>(ctx)->ranks.size() > 1)
+    return multi_registration_icp(static_cast<o3d_ctx_full *>(ctx), src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation,
+                                  with_scaling, rel_fitness, rel_rmse, max_iter, mem, out_T, out_corr, out_n_corr, out_fitness,
+                                  out_rmse, out_iters);
   DeviceGuard guard(ctx->device);
   O3D_TRY(o3d_icp_setup(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness,
                         rel_rmse, max_iter, mem, n_src));
@@ -1065,10 +1244,83 @@ int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double *nrm, co
   return o3d_voxel_down_sample_impl(ctx, xyz, nrm, col, n, voxel_size, mem, out_xyz, out_nrm, out_col, out_voxel_index, out_m);
 }
 
+}  // extern "C"
+
+// EstimateNormals over the devices of a multi context: every rank builds the grid over the whole cloud and computes the
+// normals of its contiguous range of cell-ordered points (o3d_estimate_normals_shard, one host thread per rank, no
+// exchange), rank 0 scatters the parts to the caller's order (o3d_estimate_normals_assemble).  Bit-identical to the
+// one-device call.
+static int multi_estimate_normals(o3d_ctx_full *m, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
+                                  double *normals, int has_normals) {
+  const int G = (int)m->ranks.size();
+  const int64_t rows_max = (n + G - 1) / G;
+  const size_t part_doubles = 3 * (size_t)rows_max;
+  std::vector<double> host_parts;
+  double *parts = nullptr, *packed = nullptr;
+  DeviceGuard guard0(m->device);
+  if (mem == O3D_MEM_HOST) {
+    host_parts.resize(part_doubles * (size_t)G);
+    parts = host_parts.data();
+  } else {
+    void *p = nullptr;
+    O3D_HIP(m, o3d_tmp_alloc(m, &p, sizeof(double) * part_doubles * (size_t)G));
+    parts = static_cast<double *>(p);
+  }
+  std::vector<int> status((size_t)G, O3D_OK);
+  std::vector<int64_t> ng((size_t)G, 0);
+  auto work = [&](int r) {
+    o3d_ctx *c = m->ranks[(size_t)r];
+    std::unique_lock<std::recursive_mutex> lock(static_cast<o3d_ctx_full *>(c)->mu);
+    DeviceGuard guard(c->device);
+    int st = o3d_estimate_normals_shard_impl(c, xyz, n, search_type, knn, radius, mem, has_normals ? normals : nullptr, r, G,
+                                             parts + part_doubles * (size_t)r, &ng[(size_t)r]);
+    if (st == O3D_OK && hipStreamSynchronize(c->stream) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipStreamSynchronize");
+    status[(size_t)r] = st;
+  };
+  std::vector<std::thread> threads;
+  for (int r = 1; r < G; r++) threads.emplace_back(work, r);
+  work(0);
+  for (auto &t : threads) t.join();
+  int st = O3D_OK;
+  for (int r = 0; r < G && st == O3D_OK; r++)
+    if (status[(size_t)r] != O3D_OK)
+      st = r == 0 ? status[0] : o3d_fail(m, status[(size_t)r], "rank %d (device %d): %s", r, m->ranks[(size_t)r]->device,
+                                         o3d_last_error(m->ranks[(size_t)r]));
+  if (st == O3D_OK) {
+    // the parts were written at the stride of the largest possible shard; the assembly wants them at ceil(ng / G) rows
+    const int64_t rows = (ng[0] + G - 1) / G;
+    const size_t row_doubles = 3 * (size_t)rows;
+    if (mem == O3D_MEM_HOST) {
+      if (rows != rows_max)
+        for (int r = 1; r < G; r++) memmove(parts + row_doubles * (size_t)r, parts + part_doubles * (size_t)r, sizeof(double) * row_doubles);
+      st = o3d_estimate_normals_assemble_impl(m, xyz, n, parts, G, mem, normals);
+    } else {
+      void *p = nullptr;
+      hipError_t e = o3d_tmp_alloc(m, &p, sizeof(double) * std::max<size_t>(row_doubles * (size_t)G, 1));
+      if (e != hipSuccess) st = o3d_fail(m, O3D_ERR_OOM, "EstimateNormals: %s", hipGetErrorString(e));
+      packed = static_cast<double *>(p);
+      for (int r = 0; r < G && st == O3D_OK && row_doubles > 0; r++)
+        if (hipMemcpyAsync(packed + row_doubles * (size_t)r, parts + part_doubles * (size_t)r, sizeof(double) * row_doubles,
+                           hipMemcpyDeviceToDevice, m->stream) != hipSuccess)
+          st = o3d_fail(m, O3D_ERR_HIP, "EstimateNormals: packing the parts");
+      if (st == O3D_OK) st = o3d_estimate_normals_assemble_impl(m, xyz, n, packed, G, mem, normals);
+    }
+  }
+  if (mem != O3D_MEM_HOST) {
+    o3d_tmp_free(m, parts);
+    if (packed) o3d_tmp_free(m, packed);
+  }
+  return st;
+}
+
+extern "C" {
+
 int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                          double *normals, int has_normals) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);
+  if (static_cast<o3d_ctx_full *>(ctx)->ranks.size() > 1 && n > 0 && xyz && normals)
+    return multi_estimate_normals(static_cast<o3d_ctx_full *>(ctx), xyz, n, search_type, knn, radius, mem, normals, has_normals);
   DeviceGuard guard(ctx->device);
   return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
 }

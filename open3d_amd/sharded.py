@@ -237,3 +237,78 @@ class ShardedNormals:
             parts = t.cpu().numpy()
         cloud.normals_ = self.engine.assemble(pts, parts, self.world)
         return cloud
+
+
+class ShardedMultiScaleICP:
+    """Coarse-to-fine registration (BASELINE configs 3 and 4: VoxelDownSample -> EstimateNormals -> point-to-plane ICP per
+    scale) over a process group, one process per GPU.  Per scale
+      * VoxelDownSample of both clouds runs replicated on every rank (a global sort by voxel key; its output
+        order -- ascending voxel index -- is deterministic, so every rank holds the same arrays),
+      * EstimateNormals of the target is split over the ranks (ShardedNormals: one all-gather of the parts),
+      * RegistrationICP is split by source shard (ShardedICP: one all-gather of 32 sums per iteration), starting from the
+        previous scale's transformation; the shards' correspondences are gathered so that every rank returns the whole array.
+    The same loop as pipelines.registration.MultiScaleICP, and the same results (correspondences bit for bit).
+    `downsample(cloud, voxel) -> cloud`, `icp_engine()` and `normals_engine` are injectable for the CPU tests."""
+
+    def __init__(self, icp_engine=None, normals_engine=None, downsample=None, group=None, device=None, ctx=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = device if device is not None else torch.device("cpu")
+        self.ctx = ctx
+        self.icp_engine = icp_engine or (lambda: HipEngine(ctx))
+        self.normals_engine = normals_engine
+        self.downsample = downsample or (lambda cloud, v: cloud.VoxelDownSample(v, ctx=ctx))
+
+    def _gather_corr(self, corr_shard, n_total):
+        """Shards of the correspondence array in rank order -> the whole array on every rank."""
+        if self.world == 1:
+            return np.asarray(corr_shard, dtype=np.int32)
+        per = (n_total + self.world - 1) // self.world + 1     # every shard is at most this long ([g*N/G, (g+1)*N/G))
+        buf = np.full(per, -2, np.int32)
+        buf[:len(corr_shard)] = corr_shard
+        t = self.torch.from_numpy(buf).to(self.device)
+        allt = self.torch.empty(per * self.world, dtype=t.dtype, device=self.device)
+        self.dist.all_gather_into_tensor(allt, t, group=self.group)
+        table = allt.cpu().numpy().reshape(self.world, per)
+        out = np.empty(n_total, np.int32)
+        for g in range(self.world):
+            lo, hi = shard_bounds(n_total, self.world, g)
+            out[lo:hi] = table[g, :hi - lo]
+        return out
+
+    def run(self, source, target, voxel_sizes, max_correspondence_distances=None, init=None, estimation=None, criteria=None,
+            normal_radius_factor=2.0, normal_max_nn=30, want_corr=True):
+        from .geometry import KDTreeSearchParamHybrid, PointCloud
+        from .pipelines import registration as reg
+        from . import _lib
+        estimation = estimation or reg.TransformationEstimationPointToPlane()
+        p2l = estimation.GetTransformationEstimationType() == _lib.EST_POINT_TO_PLANE
+        T = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
+        results = []
+        for k, v in enumerate(voxel_sizes):
+            src_v = self.downsample(source, v) if v > 0 else source
+            tgt_v = self.downsample(target, v) if v > 0 else target
+            if p2l and not (v <= 0 and tgt_v.HasNormals()):
+                tgt_v = PointCloud(tgt_v.points_)
+                ShardedNormals(self.normals_engine or HipNormalsEngine(self.ctx), self.group, self.device).run(
+                    tgt_v, KDTreeSearchParamHybrid(normal_radius_factor * v, normal_max_nn))
+            r = max_correspondence_distances[k] if max_correspondence_distances is not None else 2.0 * v
+            crit = criteria[k] if isinstance(criteria, (list, tuple)) else (criteria or reg.ICPConvergenceCriteria())
+            src_pts = np.ascontiguousarray(src_v.points_, dtype=np.float64)
+            n_src = len(src_pts)
+            lo, hi = shard_bounds(n_src, self.world, self.rank)
+            icp = ShardedICP(self.icp_engine(), self.group, self.device)
+            icp.setup(src_pts[lo:hi], np.ascontiguousarray(tgt_v.points_, dtype=np.float64),
+                      np.ascontiguousarray(tgt_v.normals_, dtype=np.float64) if p2l else None, r, T, estimation, crit, n_src)
+            icp.run()
+            res = icp.finish(want_corr=want_corr)
+            if want_corr:
+                res.corr_ = self._gather_corr(res.corr_, n_src)
+            res.n_source_, res.n_target_ = n_src, len(tgt_v.points_)
+            results.append(res)
+            T = res.transformation_
+        return results[-1], results

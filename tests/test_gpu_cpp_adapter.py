@@ -104,3 +104,35 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
     assert cw2.fitness_ > 0.9
     o += 19
     assert o == len(out)
+
+
+def test_cpp_adapter_over_several_devices(ctx, oracle, tmp_path):
+    """The same unchanged C++ caller with O3D_AMD_DEVICES=0,0,0 in its environment: the adapter's default context spans three
+    ranks (one GPU listed three times on this box), RegistrationICP shards the source -- same correspondences, same
+    iteration count, transformation within 1e-9 of the one-device run."""
+    if not os.path.exists(EXE):
+        pytest.fail("tests/cpp/test_adapter is missing: run __graft_entry__.build() (make -C tests/cpp)")
+    sc = make_scene(9000, 8000, cfg_id=56)
+    s = sc["spacing"]
+    nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+    fin = str(tmp_path / "in.bin")
+    with open(fin, "wb") as f:
+        f.write(np.array([len(sc["source"]), len(sc["target"])], np.int64).tobytes())
+        f.write(np.array([2 * s, 3 * s], np.float64).tobytes())
+        for a in (sc["source"], sc["target"], nrm):
+            f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    outs = []
+    for devs in (None, "0,0,0"):
+        fout = str(tmp_path / ("out_%s.bin" % (devs or "one")))
+        env = dict(os.environ)
+        env.pop("O3D_AMD_DEVICES", None)
+        if devs:
+            env["O3D_AMD_DEVICES"] = devs
+        subprocess.run([EXE, fin, fout], check=True, timeout=120, env=env)
+        outs.append(np.fromfile(fout, np.float64))
+    one, multi = outs
+    npairs = int(one[18])
+    assert int(multi[18]) == npairs and np.array_equal(one[19:19 + 2 * npairs], multi[19:19 + 2 * npairs])
+    assert rel_err(multi[:16], one[:16]) < 1e-9 and multi[16] == one[16] and rel_err(multi[17], one[17]) < 1e-9
+    ref = oracle.registration_icp(sc["source"], sc["target"], 2 * s, None, 2, nrm)
+    assert npairs == ref.n_corr

@@ -291,3 +291,63 @@ def test_sharded_normals_two_ranks(oracle, tmp_path):
     want = oracle.estimate_normals(pts, oracle.HYBRID, 30, 4 * sc["spacing"])
     a, b = (np.load(os.path.join(str(tmp_path), "nrm%d.npy" % r)) for r in range(world))
     assert np.array_equal(a, b) and np.array_equal(a, want)
+
+
+def _multiscale_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from conftest import make_scene
+    from open3d_amd import geometry
+    from open3d_amd.pipelines import registration as reg
+    from open3d_amd.sharded import ShardedMultiScaleICP
+    import oracle
+    oracle.set_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = make_scene(9000, 9001, cfg_id=91, theta_deg=1.0)
+    s = sc["spacing"]
+
+    def downsample(cloud, v):  # stand-in for PointCloud.VoxelDownSample on the GPU: the oracle's, same output order
+        return geometry.PointCloud(oracle.voxel_down_sample(cloud.points_, v)[0])
+
+    ms = ShardedMultiScaleICP(OracleEngine, OracleNormalsEngine(), downsample, None, torch.device("cpu"))
+    final, per_scale = ms.run(geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"]), [4 * s, 2 * s, 0.0],
+                              max_correspondence_distances=[8 * s, 4 * s, 2 * s], estimation=reg.TransformationEstimationPointToPlane(),
+                              criteria=reg.ICPConvergenceCriteria(), normal_radius_factor=2.0)
+    np.savez(os.path.join(tmpdir, "ms%d.npz" % rank), T=np.stack([r.transformation_ for r in per_scale]),
+             n=np.array([[r.n_source_, r.n_target_, r.iterations_] for r in per_scale]), corr=final.corr_,
+             corr1=per_scale[1].corr_)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_multiscale_two_ranks_matches_single_process(oracle, tmp_path):
+    """BASELINE configs 3 / 4 as a process-group pipeline: VoxelDownSample replicated, EstimateNormals and RegistrationICP
+    sharded, three scales (the last on the raw clouds).  Both ranks must end with the same per-scale transformations,
+    bit for bit, and with the correspondences of the single-process chain of the same calls."""
+    import torch.multiprocessing as mp
+    from conftest import make_scene
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_multiscale_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(os.path.join(str(tmp_path), "ms%d.npz" % r)) for r in range(world))
+    assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["n"], b["n"]) and np.array_equal(a["corr"], b["corr"])
+    # the same chain in one process, straight on the oracle
+    sc = make_scene(9000, 9001, cfg_id=91, theta_deg=1.0)
+    s = sc["spacing"]
+    T = np.eye(4)
+    for k, (v, r) in enumerate([(4 * s, 8 * s), (2 * s, 4 * s), (0.0, 2 * s)]):
+        src = oracle.voxel_down_sample(sc["source"], v)[0] if v > 0 else sc["source"]
+        tgt = oracle.voxel_down_sample(sc["target"], v)[0] if v > 0 else sc["target"]
+        nrm = oracle.estimate_normals(tgt, oracle.HYBRID, 30, 2.0 * v)
+        ref = oracle.registration_icp(src, tgt, r, T, 2, nrm)
+        assert (a["n"][k] == [len(src), len(tgt), ref.iterations]).all(), k
+        assert np.max(np.abs(a["T"][k] - ref.transformation)) < 1e-8, k
+        if k == 1:
+            assert np.array_equal(a["corr1"], ref.corr)
+        T = ref.transformation
+    assert np.array_equal(a["corr"], ref.corr)
+    assert np.max(np.abs(a["T"][-1] - sc["T_true"])) < 5e-3   # and it is the motion the scene was made with (noisy clouds)
