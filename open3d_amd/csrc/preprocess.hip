@@ -457,15 +457,19 @@ template <int MODE>
 __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *__restrict__ pts, int64_t p_lo, int64_t p_hi,
                                                                  const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
                                                                  double thr, double *normals, int has_normals, int by_pos,
-                                                                 const double *ref) {
+                                                                 const double *ref, const uint32_t *__restrict__ list,
+                                                                 const uint32_t *__restrict__ list_count) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
   klist_bind(l, smem, lane, knn, pts);
   l.thr = (MODE == 0) ? INFINITY : thr;
   const int max_dim = max(max(gp.nx, gp.ny), gp.nz);
+  // list != null: only the positions k_estimate_normals_hist left behind
+  const int64_t n_items = list ? (int64_t)*list_count : p_hi - p_lo;
 
-  for (int64_t p = p_lo + (int64_t)blockIdx.x * kNrmBlock + lane; p < p_hi; p += (int64_t)gridDim.x * kNrmBlock) {
+  for (int64_t it = (int64_t)blockIdx.x * kNrmBlock + lane; it < n_items; it += (int64_t)gridDim.x * kNrmBlock) {
+    const int64_t p = list ? (int64_t)list[it] : p_lo + it;
     const double4 q = pts[p];
     const size_t qi = (size_t)__double_as_longlong(q.w);
     const size_t oi = by_pos ? (size_t)(p - p_lo) : qi;
@@ -518,6 +522,253 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
             c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
             c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
           }
+        }
+      }
+    }
+    double nv[3] = {0.0, 0.0, 1.0};
+    if (k >= 3) {
+      for (int i = 0; i < 9; i++) c[i] /= (double)k;
+      double cov[9];
+      cov[0] = c[3] - c[0] * c[0];
+      cov[4] = c[6] - c[1] * c[1];
+      cov[8] = c[8] - c[2] * c[2];
+      cov[1] = cov[3] = c[4] - c[0] * c[1];
+      cov[2] = cov[6] = c[5] - c[0] * c[2];
+      cov[5] = cov[7] = c[7] - c[1] * c[2];
+      fast_eigen3x3(cov, nv);
+      if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
+        if (has_normals) { nv[0] = ref[3 * qi]; nv[1] = ref[3 * qi + 1]; nv[2] = ref[3 * qi + 2]; }
+        else { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+      }
+      if (has_normals && nv[0] * ref[3 * qi] + nv[1] * ref[3 * qi + 1] + nv[2] * ref[3 * qi + 2] < 0.0) {
+        nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0;
+      }
+    }
+    normals[3 * oi] = nv[0]; normals[3 * oi + 1] = nv[1]; normals[3 * oi + 2] = nv[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same per-point computation for hybrid search with a selection that every lane runs in lock step.  The heap of
+// k_estimate_normals makes a wavefront execute an insertion whenever ANY of its lanes has one -- for nearly every candidate
+// -- at 38 % lane utilisation, with more scalar (branch, mask) than vector instructions (profiles/r02_c_*).  Here the
+// k nearest of the candidates inside the radius are found by counting:
+//   walk 1  every candidate inside the radius is counted into one of kHistBins equal slices of [0, r^2) by its distance
+//           (a per-lane histogram of byte counters in LDS);
+//   prefix  the slice b* in which the k-th nearest lies; every candidate of a lower slice is among the k nearest;
+//   walk 2  the candidates are visited again: those of lower slices go straight to their slice's place in the list
+//           (slices are ordered, so the list is ordered up to the order inside a slice), those of slice b* to a short
+//           boundary list;
+//   finish  the boundary list is sorted by a fixed network and its first k - (number below) entries appended; the order
+//           inside the slices is repaired by odd-even transposition rounds until a round moves nothing (two or three).
+// Keys are the distances rounded to float as in the heap; equal keys are ordered by the exact fp64 distances, then by
+// original index (kl_less) -- the kept set and its order are the exact ones, the cumulants are summed in that order.
+// A lane this does not fit (more than kBoundaryCap candidates in slice b*, more than 254 inside the radius) puts its
+// point on a list that k_estimate_normals works off afterwards.
+constexpr int kHistBins = 32;
+constexpr int kBoundaryCap = 8;
+constexpr int kHistMaxKnn = 64;
+constexpr int kHistLoads = 8;
+
+__host__ __device__ constexpr size_t hist_lds_bytes(int knn) {
+  return (size_t)kNrmBlock * (8 * (size_t)knn + kHistBins + 8 * kBoundaryCap);
+}
+
+// The nine rows of the 3x3x3 block as one sequence of batches: kHistLoads consecutive candidates of the lane's current row in
+// flight, the row bookkeeping once per batch (walk_block3 does it per candidate, which costs more instructions than the
+// candidate itself; walking row by row in lock step makes every row cost its longest lane: 12.6 ms against 11.5).  The
+// slots past a row's end are padding (`pad` is any valid position, real = false).
+template <typename F>
+__device__ __forceinline__ void walk_rows(const double4 *__restrict__ pts, const uint32_t (&rs)[9], const uint32_t (&re)[9], uint32_t pad,
+                                          F &&visit) {
+  int r = 0;
+  uint32_t j = rs[0], e = re[0];
+  auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
+    while (j >= e && r < 8) {
+      r++;
+#pragma unroll
+      for (int i = 1; i < 9; i++) {
+        j = r == i ? rs[i] : j;
+        e = r == i ? re[i] : e;
+      }
+    }
+  };
+  next_row();
+  while (j < e) {
+    double4 tq[kHistLoads];
+#pragma unroll
+    for (int u = 0; u < kHistLoads; u++) tq[u] = pts[j + u < e ? j + u : pad];
+#pragma unroll
+    for (int u = 0; u < kHistLoads; u++) visit(tq[u], j + u, j + u < e);
+    j += kHistLoads;
+    next_row();
+  }
+}
+
+__global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const double4 *__restrict__ pts, int64_t p_lo, int64_t p_hi,
+                                                                      const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
+                                                                      double thr, double *normals, int has_normals, int by_pos,
+                                                                      const double *ref, uint32_t *__restrict__ fb_list,
+                                                                      uint32_t *__restrict__ fb_count) {
+  extern __shared__ unsigned char smem[];
+  const int lane = threadIdx.x;
+  // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary positions
+  float *lkey = reinterpret_cast<float *>(smem) + lane;
+  uint32_t *lpos = reinterpret_cast<uint32_t *>(smem + sizeof(float) * kNrmBlock * (size_t)knn) + lane;
+  uint32_t *hist = reinterpret_cast<uint32_t *>(smem + 8 * (size_t)kNrmBlock * (size_t)knn) + lane;
+  uint32_t *offs = hist;
+  float *bkey = reinterpret_cast<float *>(hist + (kHistBins / 4) * kNrmBlock);
+  uint32_t *bpos = reinterpret_cast<uint32_t *>(bkey + kBoundaryCap * kNrmBlock);
+  const float thrf = (float)thr;
+  const float scale = (float)kHistBins / thrf;
+  KList l;  // only for the exact tie-break of kl_less
+  l.pts = pts;
+
+  for (int64_t p = p_lo + (int64_t)blockIdx.x * kNrmBlock + lane; p < p_hi; p += (int64_t)gridDim.x * kNrmBlock) {
+    const double4 q = pts[p];
+    const size_t qi = (size_t)__double_as_longlong(q.w);
+    const size_t oi = by_pos ? (size_t)(p - p_lo) : qi;
+    const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    l.qx = q.x; l.qy = q.y; l.qz = q.z;
+    uint32_t rs[9], re[9];
+    {
+      const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
+        const bool ok = zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny;
+        const uint32_t row = ok ? ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp : 0u;
+        const uint32_t s0 = cell_start[row + (uint32_t)(xa + 1)], e0 = cell_start[row + (uint32_t)(xb + 2)];
+        rs[r] = ok ? s0 : 0u;
+        re[r] = ok ? e0 : 0u;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < kHistBins / 4; w++) hist[w * kNrmBlock] = 0u;
+    // walk 1: count
+    int n_in = 0;
+    walk_rows(pts, rs, re, (uint32_t)p, [&](const double4 &t, uint32_t, bool real) {
+      const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+      double d2 = ddx * ddx;
+      d2 = d2 + ddy * ddy;
+      d2 = d2 + ddz * ddz;
+      if (real && d2 < thr) {
+        const int bin = min((int)((float)d2 * scale), kHistBins - 1);
+        if (n_in < 255) atomicAdd(&hist[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
+        n_in++;
+      }
+    });
+    bool fb = n_in >= 255;  // a byte counter may have saturated
+    const int k_eff = min(knn, n_in);
+    // prefix: slice of the k-th nearest, number of candidates below it, first list place of every slice
+    int bstar = kHistBins, c_lo = 0;
+    {
+      int cum = 0;
+#pragma unroll
+      for (int w = 0; w < kHistBins / 4; w++) {
+        const uint32_t hw = hist[w * kNrmBlock];
+        uint32_t ow = 0;
+#pragma unroll
+        for (int b4 = 0; b4 < 4; b4++) {
+          const int c = (int)((hw >> (8 * b4)) & 255u);
+          ow |= (uint32_t)min(cum, 255) << (8 * b4);
+          if (bstar == kHistBins && cum + c >= k_eff && k_eff > 0) { bstar = 4 * w + b4; c_lo = cum; }
+          cum += c;
+        }
+        offs[w * kNrmBlock] = ow;
+      }
+    }
+    // walk 2: place
+    int nb = 0;
+    if (k_eff > 0) {
+      walk_rows(pts, rs, re, (uint32_t)p, [&](const double4 &t, uint32_t j, bool real) {
+        const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+        double d2 = ddx * ddx;
+        d2 = d2 + ddy * ddy;
+        d2 = d2 + ddz * ddz;
+        if (real && d2 < thr) {
+          const float kf = (float)d2;
+          const int bin = min((int)(kf * scale), kHistBins - 1);
+          if (bin < bstar) {
+            const uint32_t old = atomicAdd(&offs[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
+            const int dst = (int)((old >> ((bin & 3) * 8)) & 255u);
+            if (dst < knn) { lkey[dst * kNrmBlock] = kf; lpos[dst * kNrmBlock] = j; }
+          } else if (bin == bstar) {
+            if (nb < kBoundaryCap) { bkey[nb * kNrmBlock] = kf; bpos[nb * kNrmBlock] = j; }
+            nb++;
+          }
+        }
+      });
+    }
+    fb = fb || nb > kBoundaryCap;
+    // boundary slice: sort (fixed 19-comparator network for 8), append the k_eff - c_lo nearest
+    {
+      float bk[kBoundaryCap];
+      uint32_t bp[kBoundaryCap];
+#pragma unroll
+      for (int i = 0; i < kBoundaryCap; i++) {
+        const bool have = i < nb;
+        bk[i] = have ? bkey[i * kNrmBlock] : INFINITY;
+        bp[i] = have ? bpos[i * kNrmBlock] : 0xFFFFFFFFu;
+      }
+      auto ce = [&](int a, int b) {
+        const bool swap = bk[b] < bk[a] || (bk[b] == bk[a] && bp[a] != bp[b] && bk[a] != INFINITY && kl_less(l, bk[b], bp[b], bk[a], bp[a]));
+        const float ka = swap ? bk[b] : bk[a], kb = swap ? bk[a] : bk[b];
+        const uint32_t pa = swap ? bp[b] : bp[a], pb = swap ? bp[a] : bp[b];
+        bk[a] = ka; bk[b] = kb; bp[a] = pa; bp[b] = pb;
+      };
+      ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);
+      ce(0, 2); ce(1, 3); ce(4, 6); ce(5, 7);
+      ce(1, 2); ce(5, 6); ce(0, 4); ce(3, 7);
+      ce(1, 5); ce(2, 6);
+      ce(1, 4); ce(3, 6);
+      ce(2, 4); ce(3, 5);
+      ce(3, 4);
+      const int need = k_eff - c_lo;
+#pragma unroll
+      for (int i = 0; i < kBoundaryCap; i++)
+        if (i < need && c_lo + i < knn) { lkey[(c_lo + i) * kNrmBlock] = bk[i]; lpos[(c_lo + i) * kNrmBlock] = bp[i]; }
+    }
+    // order inside the slices below b*: odd-even transposition until nothing moves (wave-uniform loop)
+    {
+      bool moved = true;
+      while (__any(moved)) {
+        moved = false;
+        for (int par = 0; par < 2; par++)
+          for (int i = par; __any(i + 1 < c_lo); i += 2) {
+            if (i + 1 < c_lo) {
+              const float ka = lkey[i * kNrmBlock], kb = lkey[(i + 1) * kNrmBlock];
+              if (kb <= ka) {
+                const uint32_t pa = lpos[i * kNrmBlock], pb = lpos[(i + 1) * kNrmBlock];
+                if (kb < ka || kl_less(l, kb, pb, ka, pa)) {
+                  lkey[i * kNrmBlock] = kb; lkey[(i + 1) * kNrmBlock] = ka;
+                  lpos[i * kNrmBlock] = pb; lpos[(i + 1) * kNrmBlock] = pa;
+                  moved = true;
+                }
+              }
+            }
+          }
+      }
+    }
+    if (fb) {  // not representable here: the heap kernel takes this point
+      fb_list[atomicAdd(fb_count, 1u)] = (uint32_t)p;
+      continue;
+    }
+    const int k = k_eff;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i0 = 0; i0 < k; i0 += kHistLoads) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
+      double4 tq[kHistLoads];
+#pragma unroll
+      for (int u = 0; u < kHistLoads; u++) tq[u] = pts[lpos[min(i0 + u, k - 1) * kNrmBlock]];
+#pragma unroll
+      for (int u = 0; u < kHistLoads; u++) {
+        if (i0 + u < k) {
+          const double4 t = tq[u];
+          c[0] += t.x; c[1] += t.y; c[2] += t.z;
+          c[3] += t.x * t.x; c[4] += t.x * t.y; c[5] += t.x * t.z;
+          c[6] += t.y * t.y; c[7] += t.y * t.z; c[8] += t.z * t.z;
         }
       }
     }
@@ -952,9 +1203,9 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
   const size_t bytes = sizeof(double) * 3 * (size_t)n;
   const double *d_xyz = xyz;
   double *d_nrm = normals;
-  void *sx = nullptr, *sn = nullptr, *sp = nullptr;
+  void *sx = nullptr, *sn = nullptr, *sp = nullptr, *sf = nullptr;
   auto cleanup = [&]() {
-    for (void *b : {sx, sn, sp})
+    for (void *b : {sx, sn, sp, sf})
       if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
@@ -1006,19 +1257,32 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
       if (degenerate) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref);
+                           ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref, nullptr, nullptr);
       } else if (search_type == O3D_SEARCH_KNN) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
       } else if (search_type == O3D_SEARCH_RADIUS) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<1>, lds));
         hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+      } else if (kk <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP")) {
+        // hybrid: selection by counting (k_estimate_normals_hist); what does not fit it is left on a list for the heap kernel
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
+        uint32_t *fb_list = (uint32_t *)sf + 64, *fb_count = (uint32_t *)sf;
+        O3D_HIP(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), ctx->stream));
+        const size_t hlds = hist_lds_bytes(kk);
+        O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
+        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count);
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
+        hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 2)), dim3(kNrmBlock), lds, ctx->stream,
+                           ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,
+                           (const uint32_t *)fb_list, (const uint32_t *)fb_count);
       } else {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
       }
     }
     if (!sharded && ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);

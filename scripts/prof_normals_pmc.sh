@@ -14,5 +14,5 @@ run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run sq2 "SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"
 run sq3 "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"
-for d in sq tcp fetch write sq2 sq3; do python3 scripts/pmc_summary.py gpurun_out/pmcn_${TAG}_$d k_estimate_normals 3; done > gpurun_out/pmcn_${TAG}_summary.txt 2>&1
+for d in sq tcp fetch write sq2 sq3; do python3 scripts/pmc_summary.py gpurun_out/pmcn_${TAG}_$d ${KERNEL:-k_estimate_normals} 3; done > gpurun_out/pmcn_${TAG}_summary.txt 2>&1
 echo PMC_DONE
