@@ -265,9 +265,9 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch,
             },
         }
-        # HBM traffic per launch from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be read
-        # from inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; nearly all reads
-        # here are 16-byte loads) + WRITE_SIZE.  Only quoted for the workload it was collected on.
+        # HBM traffic per pass from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be read from
+        # inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; applied to all reads,
+        # so an upper bound) + WRITE_SIZE, summed over the two kernels of a pass.  Only quoted for the workload it was collected on.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and n == 10_000_000 and args.estimation == "p2plane" and args.search == "f32" and os.path.exists(tpath):
             with open(tpath) as f:
