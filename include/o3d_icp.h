@@ -354,6 +354,16 @@ O3D_API int o3d_registration_ransac_correspondence(o3d_ctx *ctx, const double *s
  * context.  out_pairs holds 2 * n int32 at most; returns the number of pairs. */
 O3D_API int64_t o3d_expand_correspondences(const int32_t *corr, int64_t n, int32_t *out_pairs);
 
+/* Benchmark scaffolding, no counterpart in the reference (which ships no data): the synthetic registration pair of SURVEY.md
+ * 8d -- target and source drawn independently from one analytic height field over [0, L]^2 with a splitmix64 counter stream,
+ * Gaussian noise of standard deviation `noise` on the source, the source moved by inv_T (the inverse of the transformation a
+ * registration should recover) -- generated into DEVICE buffers (3 doubles per point; d_tgt_nrm, nullable, receives the
+ * analytic unit normals of the target).  Asynchronous on the context's stream.  The same clouds as
+ * open3d_amd/synthetic.py::make_pair up to the last digits of the device's libm.  For BASELINE config 5 (4096 pairs of
+ * 200 k points: 59 GB that would otherwise cross PCIe). */
+O3D_API int o3d_synthetic_pair(o3d_ctx *ctx, int64_t n_src, int64_t n_tgt, uint64_t seed, double L, double noise,
+                               const double inv_T_colmajor[16], double *d_src, double *d_tgt, double *d_tgt_nrm);
+
 /* Tuning aid, no counterpart in the reference: best-of-reps milliseconds of one copy of `bytes` of pageable host memory to
  * (to_device = 1) or from the device, through the library's staged path (staged = 1) or plain hipMemcpyAsync. */
 O3D_API int o3d_debug_copy_bench(o3d_ctx *ctx, size_t bytes, int to_device, int staged, int reps, double *out_ms);

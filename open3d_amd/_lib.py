@@ -97,6 +97,8 @@ _SIGNATURES = {
     "o3d_estimate_normals_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                              C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "o3d_estimate_normals_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "o3d_synthetic_pair": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_double, C.c_double, c_dp, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "o3d_debug_copy_check": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int64)]),
     "o3d_expand_correspondences": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p]),
     "o3d_debug_copy_bench": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, c_dp]),

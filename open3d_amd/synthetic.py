@@ -99,3 +99,24 @@ def make_pair(n_src, n_tgt, cfg_id=0, theta_deg=0.05, tau_in_spacings=(1.0, -0.7
         "spacing": s,
         "L": L,
     }
+
+
+def make_pair_device(ctx, n_src, n_tgt, cfg_id=0, theta_deg=0.05, tau_in_spacings=(1.0, -0.7, 0.5), noise_in_spacings=0.1, L=None,
+                     want_normals=True, device=None):
+    """make_pair generated on the GPU (o3d_synthetic_pair) into torch tensors: dict(source, target, normals, T_true, spacing,
+    L).  The same clouds up to the last digits of the device's sin / cos / log."""
+    import torch
+    from . import _lib
+    seed = (int(0x9E3779B97F4A7C15) ^ int(cfg_id)) & 0xFFFFFFFFFFFFFFFF
+    if L is None:
+        L = extent_for(n_tgt)
+    s = L / np.sqrt(float(n_tgt))
+    T_true = rigid_transform(theta_deg, np.asarray(tau_in_spacings, dtype=np.float64) * s)
+    Tinv = np.linalg.inv(T_true)
+    dev = device if device is not None else torch.device("cuda", ctx.device)
+    src = torch.empty((n_src, 3), dtype=torch.float64, device=dev)
+    tgt = torch.empty((n_tgt, 3), dtype=torch.float64, device=dev)
+    nrm = torch.empty((n_tgt, 3), dtype=torch.float64, device=dev) if want_normals else None
+    ctx.check(ctx._lib.o3d_synthetic_pair(ctx.handle, n_src, n_tgt, seed, float(L), float(noise_in_spacings * s),
+                                          _lib.colmajor(Tinv).ctypes.data_as(_lib.c_dp), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(nrm)))
+    return {"source": src, "target": tgt, "normals": nrm, "T_true": T_true, "spacing": s, "L": L}

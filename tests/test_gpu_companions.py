@@ -310,3 +310,60 @@ def test_sharded_batch_runner_on_one_gpu(ctx):
     for a, b in zip(got, want):
         assert np.array_equal(a.transformation_, b.transformation_)
         assert a.fitness_ == b.fitness_ and a.inlier_rmse_ == b.inlier_rmse_ and a.iterations_ == b.iterations_
+
+
+def test_device_scene_generator_matches_numpy(ctx):
+    """o3d_synthetic_pair (benchmark scaffolding for config 5): the same clouds as synthetic.make_pair up to the device's
+    libm -- same counter stream, same Box-Muller pairing, same inverse motion."""
+    import torch
+    from open3d_amd import synthetic
+    for n_src, n_tgt, noise in ((5001, 7000, 0.1), (300, 200, 0.0)):
+        want = synthetic.make_pair(n_src, n_tgt, cfg_id=1234, theta_deg=0.7, L=6.0, noise_in_spacings=noise)
+        got = synthetic.make_pair_device(ctx, n_src, n_tgt, cfg_id=1234, theta_deg=0.7, L=6.0, noise_in_spacings=noise)
+        torch.cuda.synchronize()
+        assert np.abs(got["target"].cpu().numpy() - want["target"]).max() < 1e-13
+        assert np.abs(got["source"].cpu().numpy() - want["source"]).max() < 1e-12
+        nrm = synthetic.surface_normals(want["target"][:, 0], want["target"][:, 1])
+        assert np.abs(got["normals"].cpu().numpy() - nrm).max() < 1e-13
+        assert np.array_equal(got["T_true"], want["T_true"]) and got["spacing"] == want["spacing"]
+
+
+def test_batch_of_200k_pairs_matches_single_calls(ctx, oracle):
+    """BASELINE config 5 shape (200 k x 200 k, point-to-plane, 30 fixed iterations), clouds generated on the device: a
+    handful of pairs through o3d_registration_icp_batch with 4 workers must equal their single calls bit for bit, and one
+    of them the oracle."""
+    import ctypes as C
+    import torch
+    from open3d_amd import _lib, synthetic
+    n, npairs = 200_000, 6
+    pairs = [synthetic.make_pair_device(ctx, n, n, cfg_id=5000 + k, L=2.83) for k in range(npairs)]
+    torch.cuda.synchronize()
+    s = pairs[0]["spacing"]
+    VP, I64 = C.c_void_p * npairs, C.c_int64 * npairs
+    a_src = VP(*[p["source"].data_ptr() for p in pairs])
+    a_tgt = VP(*[p["target"].data_ptr() for p in pairs])
+    a_nrm = VP(*[p["normals"].data_ptr() for p in pairs])
+    cnt = I64(*[n] * npairs)
+    corr = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(npairs)]
+    a_corr = VP(*[c.data_ptr() for c in corr])
+    T = np.zeros((npairs, 16)); nc = np.zeros(npairs, np.int64); fit = np.zeros(npairs); rmse = np.zeros(npairs)
+    iters = np.zeros(npairs, np.int32); status = np.zeros(npairs, np.int32)
+    ctx.check(ctx._lib.o3d_registration_icp_batch(ctx.handle, npairs, a_src, cnt, a_tgt, a_nrm, cnt, 2 * s, None, _lib.EST_POINT_TO_PLANE, 0,
+                                                  0.0, 0.0, 30, _lib.MEM_DEVICE, 4, _lib.ptr(T), a_corr, _lib.ptr(nc), _lib.ptr(fit),
+                                                  _lib.ptr(rmse), _lib.ptr(iters), _lib.ptr(status)))
+    assert not status.any() and (iters == 30).all()
+    for k in range(npairs):
+        p = pairs[k]
+        T1 = np.zeros(16); c1 = torch.empty(n, dtype=torch.int32, device="cuda")
+        nc1, f1, r1, it1 = C.c_int64(), C.c_double(), C.c_double(), C.c_int()
+        ctx.check(ctx._lib.o3d_registration_icp(ctx.handle, _lib.ptr(p["source"]), n, _lib.ptr(p["target"]), _lib.ptr(p["normals"]), n, 2 * s,
+                                                _lib.colmajor(np.eye(4)).ctypes.data_as(_lib.c_dp), 2, 0, 0.0, 0.0, 30, _lib.MEM_DEVICE,
+                                                T1.ctypes.data_as(_lib.c_dp), _lib.ptr(c1), C.byref(nc1), C.byref(f1), C.byref(r1), C.byref(it1)))
+        assert np.array_equal(T[k], T1) and nc[k] == nc1.value and fit[k] == f1.value and rmse[k] == r1.value
+        assert torch.equal(corr[k], c1)
+        assert np.abs(_lib.from_colmajor(T[k]) - p["T_true"]).max() < 1e-3
+    p = pairs[2]
+    ref = oracle.registration_icp(p["source"].cpu().numpy(), p["target"].cpu().numpy(), 2 * s, None, 2, p["normals"].cpu().numpy(),
+                                  rel_fitness=0.0, rel_rmse=0.0, max_iter=30)
+    assert np.array_equal(corr[2].cpu().numpy(), ref.corr)
+    assert np.abs(_lib.from_colmajor(T[2]) - ref.transformation).max() < 1e-6
