@@ -394,6 +394,8 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   for (hipEvent_t e : ctx->prof_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->poll_ev) (void)hipEventDestroy(ctx->poll_ev);
+  for (hipEvent_t e : ctx->setup_ev)
+    if (e) (void)hipEventDestroy(e);
   o3d_tmp_release_all(ctx);
   o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -462,15 +464,11 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   DeviceGuard guard(ctx->device);
   o3d_staging *sg = staging_of(ctx);
 
-  struct Events {  // destroyed on every return path
-    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
-    ~Events() {
-      for (hipEvent_t x : e)
-        if (x) (void)hipEventDestroy(x);
-    }
-    hipEvent_t &operator[](int i) { return e[i]; }
-  } ev;
-  for (auto &e : ev.e) O3D_HIP(ctx, hipEventCreate(&e));
+  // three events kept on the context: set-up timing is read lazily by o3d_icp_get_setup_ms (a read here would drain the
+  // stream once more per call; the batch workers make thousands of small calls)
+  hipEvent_t *ev = ctx->setup_ev;
+  for (int k = 0; k < 3; k++)
+    if (!ev[k]) O3D_HIP(ctx, hipEventCreate(&ev[k]));
   O3D_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream));
 
@@ -560,13 +558,9 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   hs->radius = sqrt(diag2);
   // certificates hold while a query moves less than about half the slack its bound was given (the search's extra reach)
   hs->cert_skip_above = 0.5 * ctx->cert_gap * ctx->gp.h;
+  // (the staging page is rewritten by the next set-up on this context at the earliest, and every path to it --
+  // o3d_icp_finish, o3d_icp_poll, o3d_icp_fetch, an error -- has synchronised the stream by then)
   O3D_HIP(ctx, o3d_h2d(ctx, ctx->state, hs, sizeof(IcpState)));
-  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  float ms0 = 0, ms1 = 0;
-  (void)hipEventElapsedTime(&ms0, ev[0], ev[1]);
-  (void)hipEventElapsedTime(&ms1, ev[1], ev[2]);
-  ctx->setup_ms[0] = ms0;
-  ctx->setup_ms[1] = ms1;
   ctx->enq_passes = 0;
   ctx->sums_valid = 0;
   ctx->hyp_mode = 0;
@@ -580,8 +574,13 @@ int o3d_icp_setup(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, const doub
   if (!ctx) return O3D_ERR_INVALID_ARG;
   if (estimation != O3D_EST_POINT_TO_POINT && estimation != O3D_EST_POINT_TO_PLANE)
     return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "estimation type %d is not on the device path of o3d_icp_setup", estimation);
-  return icp_setup_impl(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness, rel_rmse,
-                        max_iter, mem, n_src_global, nullptr, nullptr, 0.0, nullptr);
+  O3D_TRY(icp_setup_impl(ctx, src_xyz, n_src, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation, with_scaling, rel_fitness, rel_rmse,
+                         max_iter, mem, n_src_global, nullptr, nullptr, 0.0, nullptr));
+  if (mem == O3D_MEM_HOST) {  // the caller's host buffers are free when this returns; device buffers are read in stream order
+    DeviceGuard guard(ctx->device);
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return O3D_OK;
 }
 
 int o3d_icp_pass(o3d_ctx *ctx) {
@@ -777,8 +776,16 @@ int o3d_icp_get_log(o3d_ctx *ctx, double *host_log, int max_rows, int *out_rows)
 int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
   if (!ctx || !out_ms) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);
-  out_ms[0] = ctx->setup_ms[0];
-  out_ms[1] = ctx->setup_ms[1];
+  out_ms[0] = out_ms[1] = 0.0;
+  if (ctx->setup_ev[0] && ctx->setup_ev[1] && ctx->setup_ev[2]) {
+    DeviceGuard guard(ctx->device);
+    O3D_HIP(ctx, hipEventSynchronize(ctx->setup_ev[2]));
+    float ms0 = 0, ms1 = 0;
+    (void)hipEventElapsedTime(&ms0, ctx->setup_ev[0], ctx->setup_ev[1]);
+    (void)hipEventElapsedTime(&ms1, ctx->setup_ev[1], ctx->setup_ev[2]);
+    out_ms[0] = ms0;
+    out_ms[1] = ms1;
+  }
   return O3D_OK;
 }
 
@@ -850,6 +857,22 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
                                   int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
   const int G = (int)m->ranks.size();
   if (n_src < 0 || max_iter < 0) return o3d_fail(m, O3D_ERR_INVALID_ARG, "bad sizes");
+  // Ranks on the SAME device (a rehearsal of the sharded path on one GPU) enqueue on one stream, that of the first of
+  // them: behind the host barrier every rank's sums are then ahead of every rank's solve in stream order, and no event is
+  // needed between them.  (Cross-stream events between many streams of one device -- they share its four hardware queues
+  // -- were seen to stall once in a long test process; between devices every stream has a queue of its own.)
+  std::vector<int> leader((size_t)G, 0);
+  for (int r = 0; r < G; r++) {
+    leader[(size_t)r] = r;
+    for (int f = 0; f < r; f++)
+      if (m->ranks[(size_t)f]->device == m->ranks[(size_t)r]->device) { leader[(size_t)r] = f; break; }
+    if (leader[(size_t)r] != r) {
+      o3d_ctx *c = m->ranks[(size_t)r];
+      DeviceGuard guard(c->device);
+      O3D_HIP(m, hipStreamSynchronize(c->stream));
+      c->stream = m->ranks[(size_t)leader[(size_t)r]]->stream;
+    }
+  }
   HostBarrier bar(G);
   std::atomic<int> failed(0), stop(0);
   std::vector<int> status((size_t)G, O3D_OK);
@@ -884,8 +907,9 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
           pending = false;
         }
         if (!sync_point() || stop.load()) break;
-        for (int q = 0; q < G && st == O3D_OK; q++)
-          if (q != r && hipStreamWaitEvent(c->stream, m->xev[(size_t)(par * G + q)], 0) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipStreamWaitEvent");
+        for (int q = 0; q < G && st == O3D_OK; q++)  // the sums of the ranks on other devices (same device: same stream)
+          if (m->ranks[(size_t)q]->device != c->device && hipStreamWaitEvent(c->stream, m->xev[(size_t)(par * G + q)], 0) != hipSuccess)
+            st = o3d_fail(c, O3D_ERR_HIP, "hipStreamWaitEvent");
         if (st == O3D_OK) st = o3d_icp_solve(c, box + (size_t)par * G * O3D_NSUMS, G);
         if (r == 0 && st == O3D_OK && can_break && it % kChunk == kChunk - 1 && it < max_iter) {
           if (hipMemcpyAsync((void *)flag, &c->state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -907,6 +931,8 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
   for (int r = 1; r < G; r++) threads.emplace_back(work, r);
   work(0);
   for (auto &t : threads) t.join();
+  for (int r = 1; r < G; r++)  // back to the streams of their own
+    if (leader[(size_t)r] != r) m->ranks[(size_t)r]->stream = m->ranks[(size_t)r]->own_stream;
   for (int r = 0; r < G; r++)
     if (status[(size_t)r] != O3D_OK) {
       if (r == 0) return status[0];  // its message is already on this context

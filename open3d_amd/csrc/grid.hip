@@ -488,7 +488,7 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
                      ctx->src_sorted);
   O3D_HIP(ctx, hipGetLastError());
-  // the pinned staging for T must stay valid until the copy has run
-  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (the pinned staging for T is rewritten by the next set-up on this context at the earliest; every path to it has
+  // synchronised the stream by then)
   return O3D_OK;
 }

@@ -116,7 +116,7 @@ struct o3d_ctx {
   int sums_valid = 0;  // ctx->sums holds the sums of the last pass (o3d_icp_fetch)
   int estimation = 0;
   double thr = 0;  // (double)(float)(r*r)
-  double setup_ms[2] = {0, 0};
+  hipEvent_t setup_ev[3] = {nullptr, nullptr, nullptr};  // start, grid built, source sorted (o3d_icp_get_setup_ms)
   int has_tgt_normals = 0;
 
   // optional HIP-event profile of k_icp_pass
