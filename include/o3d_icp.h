@@ -64,6 +64,9 @@ typedef enum { O3D_EST_POINT_TO_POINT = 1, O3D_EST_POINT_TO_PLANE = 2, O3D_EST_C
 typedef enum { O3D_SEARCH_KNN = 0, O3D_SEARCH_RADIUS = 1, O3D_SEARCH_HYBRID = 2 } o3d_search;
 
 /* ---- context -------------------------------------------------------------- */
+/* One GPU, one stream, and the device memory of the calls made on it: grid, sorted source and sort buffers (grow-only) and,
+ * for calls on host buffers, up to 16 GiB of idle device blocks kept from earlier calls for reuse (hipMalloc / hipFree cost
+ * milliseconds per call).  Everything is returned by o3d_ctx_destroy; nothing is freed before that. */
 O3D_API int o3d_ctx_create(int device_id, o3d_ctx **out_ctx);
 /* One context over several GPUs of the node (no reference counterpart: the reference is single-process CPU code; SURVEY.md
  * 8e).  The context is rank 0 (device_ids[0]) and behaves like an ordinary context in every entry point; in addition
