@@ -299,6 +299,9 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   if ((e = hipMalloc((void **)&ctx->counters, sizeof(unsigned long long) * O3D_NCOUNTERS)) != hipSuccess) return bail(e, "hipMalloc counters");
   if ((e = hipMalloc((void **)&ctx->work_count, sizeof(uint32_t) * 8 * O3D_MAX_GRID)) != hipSuccess) return bail(e, "hipMalloc work_count");
   if ((e = hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+  if ((e = hipMalloc((void **)&ctx->gsums, sizeof(double) * O3D_NSUMS * 32 + sizeof(unsigned) * 64)) != hipSuccess) return bail(e, "hipMalloc gsums");
+  ctx->tickets = reinterpret_cast<unsigned *>(ctx->gsums + O3D_NSUMS * 32);
+  if ((e = hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * 64, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
   // the scratch address of o3d_compute_transformation_noalloc on this device, so that its first call may come under capture
   if (o3d_noalloc_prepare_device(device_id) != O3D_OK) return bail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
   *out_ctx = ctx;
@@ -381,7 +384,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters};
+                  ctx->counters,   ctx->gsums};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -523,7 +526,11 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   }
   ctx->search_grid = (int)gs;
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
-  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : 1;  // tuning aid
+  // Certificates cost a launch and a pass over the source of their own: they pay from a few hundred thousand points on
+  // (steady-state iteration at 200 k points 26 us without, 31 us with; at 1 M 61 us without, 51 us with).
+  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : (n_src >= 400000 ? 1 : 0));  // tuning aids
+  ctx->use_tail = getenv("O3D_NO_TAIL") ? 0 : 1;  // tuning aid
+  O3D_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * 64, ctx->stream));  // (they return to zero by themselves)
   if (const char *e = getenv("O3D_CERT_GAP")) {
     const double v = atof(e);
     if (v >= 0.0 && v <= 1.0) ctx->cert_gap = v;

@@ -293,6 +293,16 @@ struct PassArgs {
   int cert_row0;   // first partial row of k_icp_cert (the rows of k_icp_search_coop come first)
   double *partials;
   double thr;
+  // the pass's last kernel ends the pass itself (pass_tail): 0 = no, 1 = sum the partial rows, 2 = ... and run the estimate
+  int tail;
+  int nparts;            // partial rows of the pass
+  int has_normals;
+  int log_rows;
+  unsigned *tickets;     // 33 arrival counters, all zero between launches
+  double *gsums;         // 32 rows of O3D_NSUMS: one per group of workgroups
+  double *sums_out;      // the pass's 32 sums
+  double *log;
+  IcpState *st_rw;
   // coloured ICP only (ColoredICP.cpp:125-177)
   const double4 *tcol;  // per sorted target point: {intensity, colour gradient}
   const double *sint;   // per processing position: source intensity
@@ -309,6 +319,20 @@ __device__ __forceinline__ double uniform_f64(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+
+// Device-scope accesses: written through to / read from where every XCD sees them (see pass_tail).
+__device__ __forceinline__ double load_device_coherent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_device_coherent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Defined behind the estimate's algebra below.  Every thread of the workgroup calls it once the workgroup's partial row
+// has been stored.
+__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk);
 
 __device__ __forceinline__ void load_update(const IcpState *st, double (&T)[12], double (&w)[4]) {
 #pragma unroll
@@ -493,7 +517,7 @@ __device__ __forceinline__ void mfma_reduce_store(const v4f64 &S, double (*red)[
         for (int d = 0; d < 3; d++) v += ((red[0][d][d] + red[1][d][d]) + red[2][d][d]) + red[3][d][d];
       }
     }
-    partials[(size_t)chunk * O3D_NSUMS + k] = v;
+    store_device_coherent(partials + (size_t)chunk * O3D_NSUMS + k, v);  // pass_tail may read it from another XCD
   }
 }
 
@@ -1070,6 +1094,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   if (nq > 0) consume();
   __syncthreads();
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
+  pass_tail(a, reinterpret_cast<double *>(wls), wr.chunk);
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -1489,6 +1514,94 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize_solve(const do
   if (threadIdx.x == 0) solve_body(&ls, s[0], has_normals, log, log_rows);
   __syncthreads();
   state_copy(reinterpret_cast<uint32_t *>(st), reinterpret_cast<const uint32_t *>(&ls));
+}
+
+// The end of a pass without a launch of its own.  The workgroups of the pass's last kernel are dealt into 32 groups by
+// partial row (chunk & 31); the LAST workgroup of a group to store its row adds the group's rows, and the last GROUP to
+// finish adds the 32 group rows and, in the device-resident loop, runs the estimate.  "Last" is decided by an arrival
+// counter; nobody waits for anybody.  WHO does the adding varies from run to run, WHAT is added in which order does not:
+// group g owns rows g + 32 u + 1024 j and adds them exactly as finalize_sums does (pairwise over u, then over j; then the
+// groups in order), so the sums equal k_icp_finalize's bit for bit.
+// Visibility between workgroups on different XCDs (one L2 each) without device-wide fences -- a release fence writes back
+// the whole L2 and an acquire fence invalidates it, tens of microseconds over a pass's workgroups (measured: 28 -> 55 us per
+// iteration at 100 k points): the rows are stored and loaded with device-scope accesses (write-through / read-through,
+// sc1), a workgroup arrives only after its stores have been acknowledged (s_waitcnt), and the loads of the last one depend
+// on the counter value it drew.
+__device__ __forceinline__ bool last_to_arrive(unsigned *ticket, unsigned expected) {
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);  // this wavefront's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // nobody else touches it before the next launch
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk) {
+  if (!a.tail) return;
+  const int tid = threadIdx.x, k = tid & 31, uq = tid >> 5;
+  const unsigned g = chunk & 31u;
+  const unsigned ngroups = gridDim.x < 32u ? gridDim.x : 32u;
+  if (!last_to_arrive(a.tickets + g, (gridDim.x - g + 31u) / 32u)) return;
+  double (*s8)[O3D_NSUMS] = reinterpret_cast<double (*)[O3D_NSUMS]>(lds);
+  double acc = 0.0;
+  for (int b0 = (int)g; b0 < a.nparts; b0 += 32 * 32) {  // workgroup-uniform
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int b = b0 + 32 * (4 * uq + u);
+      v[u] = b < a.nparts ? load_device_coherent(a.partials + (size_t)b * O3D_NSUMS + k) : 0.0;
+    }
+    v[0] += v[1]; v[2] += v[3]; v[0] += v[2];
+    __syncthreads();
+    s8[uq][k] = v[0];
+    __syncthreads();
+    if (tid < O3D_NSUMS) {
+      double t[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) t[q] = s8[q][k];
+      t[0] += t[1]; t[2] += t[3]; t[4] += t[5]; t[6] += t[7];
+      t[0] += t[2]; t[4] += t[6];
+      t[0] += t[4];
+      acc += t[0];
+    }
+  }
+  if (tid < O3D_NSUMS) store_device_coherent(a.gsums + g * O3D_NSUMS + k, acc);
+  if (!last_to_arrive(a.tickets + 32, ngroups)) return;
+  __shared__ double q[O3D_NSUMS];
+  if (tid < O3D_NSUMS) {
+    double v[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      if ((unsigned)r < ngroups) {
+        v[r] = load_device_coherent(a.gsums + r * O3D_NSUMS + k);
+      } else {
+        // a grid of fewer than 32 workgroups: group r has no member; its rows -- at most r and r + 32, both rows of
+        // k_icp_cert, complete before this kernel began -- are added here, again as finalize_sums would
+        const double x0 = r < a.nparts ? a.partials[(size_t)r * O3D_NSUMS + k] : 0.0;
+        const double x1 = r + 32 < a.nparts ? a.partials[(size_t)(r + 32) * O3D_NSUMS + k] : 0.0;
+        v[r] = 0.0 + (x0 + x1);
+      }
+    }
+    double t = v[0];
+#pragma unroll
+    for (int r = 1; r < 32; r++) t += v[r];
+    q[k] = t;
+    a.sums_out[k] = t;
+  }
+  if (a.tail < 2) return;
+  __shared__ IcpState ls;
+  state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(a.st_rw));
+  __syncthreads();
+  if (tid >= O3D_WAVE && tid < 2 * O3D_WAVE) write_log_row(&ls, q, a.log, a.log_rows, tid - O3D_WAVE);
+  __syncthreads();
+  if (tid == 0) solve_body(&ls, q, a.has_normals, a.log, a.log_rows);
+  __syncthreads();
+  state_copy(reinterpret_cast<uint32_t *>(a.st_rw), reinterpret_cast<const uint32_t *>(&ls));
 }
 
 __global__ __launch_bounds__(O3D_BLOCK) void k_scatter_corr(const int32_t *__restrict__ corr_sorted, const uint32_t *__restrict__ perm,
@@ -1934,6 +2047,11 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     O3D_LAUNCH_EST(k_icp_cert, grows, pa);
     nparts = 2 * grows;
   }
+  // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
+  const bool tail = fused && ctx->use_tail;
+  pa.tail = tail ? (fuse_solve ? 2 : 1) : 0;
+  pa.nparts = nparts; pa.has_normals = ctx->has_tgt_normals; pa.log_rows = ctx->log_rows; pa.log = ctx->log;
+  pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
   if (fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
     O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
@@ -1946,7 +2064,8 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 2], ctx->stream));
     ctx->prof_n++;
   }
-  if (fuse_solve)
+  if (tail) {
+  } else if (fuse_solve)
     hipLaunchKernelGGL(k_icp_finalize_solve, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, nparts, ctx->state,
                        dev_sums_out, ctx->has_tgt_normals, ctx->log, ctx->log_rows);
   else

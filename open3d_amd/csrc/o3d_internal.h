@@ -88,6 +88,8 @@ struct o3d_ctx {
   float *lb_sorted = nullptr;      // per processing position: lower bound on the distance to every OTHER target point
   uint32_t *work = nullptr;        // work list of the search kernel (k_icp_cert), one segment per wavefront
   uint32_t *work_count = nullptr;  // one counter per segment (4 per workgroup)
+  double *gsums = nullptr;         // pass_tail: 32 group rows of O3D_NSUMS, then (same allocation) ...
+  unsigned *tickets = nullptr;     // ... 64 arrival counters, zero between launches
   size_t cap_src = 0;
   double *src_orig = nullptr;      // hypothesis mode: the source in processing order, never transformed
   size_t cap_src_orig = 0;
@@ -108,6 +110,7 @@ struct o3d_ctx {
   int pass_grid = 0;    // workgroups of the accumulate / per-lane search kernels (one partial row each)
   int search_grid = 0;  // workgroups of k_icp_search_coop
   int use_seed = 1;     // k_icp_search_coop: previous match as the first pruning bound (O3D_NO_SEED=1 turns it off)
+  int use_tail = 1;     // the search kernel's last workgroups end the pass (O3D_NO_TAIL=1: separate finalize / solve launch)
   int use_cert = 1;     // k_icp_search_coop: certified previous matches skip the search (O3D_NO_CERT=1 turns it off)
   double cert_gap = 0.0625;  // extra search reach for the certificates' slack, in cells (O3D_CERT_GAP)
   int icp_ready = 0;

@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library uses certificates (k_icp_cert) from 400 k source points on; the GPU tests are mostly smaller than that and are
+# there to exercise them, so the suite turns them on at every size (O3D_NO_CERT, where a test sets it, still wins;
+# test_gpu_tail.py::test_certificate_size_policy checks the default).
+os.environ.setdefault("O3D_CERT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -1,0 +1,104 @@
+"""The end of a pass inside the search kernel (icp.hip: pass_tail -- the last workgroups to arrive add the partial rows and
+run the estimate) against the separate k_icp_finalize_solve launch it replaces (O3D_NO_TAIL=1): which workgroup arrives last
+changes from run to run, what is added in which order must not.  Bar: the per-pass log (fitness, rmse, count, sum of squares,
+transformation, all 32 sums), the final transformation and the correspondences are IDENTICAL bit for bit, for grids of one
+group member each (8 workgroups), partly filled groups and the full 1024-workgroup grid, with and without certificates."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, sc, nrm, est, r, iters, env):
+    from open3d_amd.pipelines import registration as reg
+    old = {k: os.environ.get(k) for k in ("O3D_NO_TAIL", "O3D_NO_CERT", "O3D_CERT")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        sess = reg.IcpSession(ctx).setup(sc["source"], sc["target"], nrm, r, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, iters))
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    sess.run()
+    res = sess.finish()
+    return res, sess.log()
+
+
+@pytest.mark.parametrize("n", [1_000, 70_000, 300_000, 1_500_000])
+@pytest.mark.parametrize("est_name", ["p2p", "p2plane"])
+def test_pass_tail_equals_separate_finalize_solve(ctx, n, est_name):
+    from open3d_amd.pipelines import registration as reg
+    from open3d_amd import synthetic
+    sc = make_scene(n, n - n // 10, cfg_id=300 + n % 97, theta_deg=0.3)
+    s = sc["spacing"]
+    nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+    est, r = ((reg.TransformationEstimationPointToPoint(True), 3 * s) if est_name == "p2p"
+              else (reg.TransformationEstimationPointToPlane(), 2 * s))
+    for cert_env in ({"O3D_CERT": "1"}, {"O3D_NO_CERT": "1"}):
+        want, want_log = _run(ctx, sc, nrm, est, r, 12, dict(cert_env, O3D_NO_TAIL="1"))
+        for rep in range(3):   # who arrives last differs between repetitions
+            got, got_log = _run(ctx, sc, nrm, est, r, 12, cert_env)
+            assert got.iterations_ == want.iterations_ == 12
+            assert np.array_equal(got_log, want_log)
+            assert np.array_equal(got.transformation_, want.transformation_)
+            assert np.array_equal(got.corr_, want.corr_)
+            assert got.fitness_ == want.fitness_ and got.inlier_rmse_ == want.inlier_rmse_
+
+
+def test_pass_tail_in_the_stepwise_sharded_form(ctx):
+    """o3d_icp_pass_to (sums only, the estimate is the caller's): the tail writes the same 32 sums as k_icp_finalize."""
+    import torch
+    from open3d_amd.pipelines import registration as reg
+    from open3d_amd import synthetic
+    sc = make_scene(120_000, 100_000, cfg_id=17)
+    s = sc["spacing"]
+    nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+    out = []
+    for env in ({"O3D_NO_TAIL": "1"}, {}):
+        old = os.environ.get("O3D_NO_TAIL")
+        os.environ.pop("O3D_NO_TAIL", None)
+        os.environ.update(env)
+        try:
+            sess = reg.IcpSession(ctx).setup(sc["source"], sc["target"], nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
+                                             reg.ICPConvergenceCriteria(0.0, 0.0, 5))
+        finally:
+            os.environ.pop("O3D_NO_TAIL", None)
+            if old is not None:
+                os.environ["O3D_NO_TAIL"] = old
+        sums = torch.zeros(5, 32, dtype=torch.float64, device="cuda")
+        for it in range(5):
+            sess.enqueue_pass_to(sums[it].data_ptr())
+            sess.enqueue_solve(sums[it].data_ptr(), 1)
+        torch.cuda.synchronize()
+        out.append((sums.cpu().numpy(), sess.finish().transformation_))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_certificate_size_policy(ctx):
+    """Without O3D_CERT / O3D_NO_CERT certificates are used from 400 k source points on, and the result does not depend on
+    it: below, the counters show none; above, most of the later passes' queries."""
+    from open3d_amd.pipelines import registration as reg
+    from open3d_amd import synthetic
+    for n, expect in ((150_000, False), (450_000, True)):
+        sc = make_scene(n, n, cfg_id=5, theta_deg=0.2)
+        s = sc["spacing"]
+        nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+        est = reg.TransformationEstimationPointToPlane()
+        ctx.debug_set(collect_tile_stats=True)
+        try:
+            ctx.tile_stats(reset=True)
+            got, _ = _run(ctx, sc, nrm, est, 2 * s, 10, {})
+            certified = ctx.tile_stats(reset=True)["certified"]
+            other, _ = _run(ctx, sc, nrm, est, 2 * s, 10, {"O3D_NO_CERT": "1"} if expect else {"O3D_CERT": "1"})
+        finally:
+            ctx.debug_set(collect_tile_stats=False)
+        assert (certified > 3 * n) if expect else (certified == 0), certified
+        assert np.array_equal(got.corr_, other.corr_)
+        assert np.abs(got.transformation_ - other.transformation_).max() < 1e-12
