@@ -251,7 +251,7 @@ def main():
                 "bound": "hbm",
                 "kernel": "k_icp_cert (update in place + certified previous matches + MFMA sums) and k_icp_search_coop (exact "
                           "correspondence search of what is left + MFMA sums): the two kernels of an ICP pass; "
-                          "k_icp_finalize_solve follows.  HIP events on the launch stream"
+                          "the second one also ends the pass (its last workgroups add the partial rows and solve the 6x6 system: no third launch).  HIP events on the launch stream"
                           if args.search == "f32" else "k_icp_search + k_icp_accumulate_mfma (all-fp64 path)",
                 "cert_kernel_ms" if args.search == "f32" else "search_kernel_ms": search_ms,
                 "search_kernel_ms" if args.search == "f32" else "second_kernel_ms": second_ms,

@@ -18,7 +18,7 @@ from open3d_amd import _lib, synthetic  # noqa: E402
 
 npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 workers = [int(w) for w in sys.argv[2:]] or [8]
-n = 200_000
+n = int(os.environ.get("C5_POINTS", "200000"))   # (other sizes: a tuning experiment, not config 5)
 ctx = _lib.Context(0)
 dev = torch.device("cuda", 0)
 t0 = time.perf_counter()
