@@ -245,6 +245,10 @@ O3D_API int o3d_icp_profile_read_all(o3d_ctx *ctx, double *out_ms, int max_count
  * read by o3d_debug_tile_stats). */
 O3D_API int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats);
 O3D_API int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset);
+/* The cell table of the last grid built on the context: {cell side, nx, ny, nz, padded row length, margin cells, 1 if the
+ * cooperative fp32-prefilter search is in use (0: the per-lane fp64 search), points in the grid, cells per brick side
+ * (0: dense table), bricks stored}. */
+O3D_API int o3d_debug_grid_info(const o3d_ctx *ctx, double out[10]);
 /* Test hook, no reference counterpart: sets THIS context's count of fp32 winners whose fp64 confirmation failed, as the
  * search kernel would; the next o3d_icp_finish / o3d_icp_fetch on this context (and on no other) then returns
  * O3D_ERR_STATE.  The counter is cleared by o3d_icp_setup and by the call that reports it. */

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "o3d_icp_pass_to": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_debug_set": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "o3d_debug_tile_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
+    "o3d_debug_grid_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "o3d_debug_inject_bound_violation": (C.c_int, [C.c_void_p, C.c_uint]),
     "o3d_debug_get_source_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -218,6 +219,12 @@ class Context:
         self.check(self._lib.o3d_debug_tile_stats(self._h, out, int(reset)))
         keys = ["wave_iters", "item_trips", "runs", "exact_lanes", "items", "valid_lanes", "certified", "_7"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def grid_info(self):
+        out = (C.c_double * 10)()
+        self.check(self._lib.o3d_debug_grid_info(self._h, out))
+        keys = ["cell_side", "nx", "ny", "nz", "row_length", "margin", "cooperative_search", "points", "brick_side", "bricks"]
+        return dict(zip(keys, [float(v) for v in out]))
 
     @property
     def handle(self):

@@ -384,7 +384,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters,   ctx->gsums};
+                  ctx->counters,   ctx->gsums,      ctx->brick_dir};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -495,7 +495,8 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     ctx->slg = sqrt(lambda_geometric);
     ctx->slp = sqrt(1.0 - lambda_geometric);
   }
-  O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist));
+  ctx->use_bricks = getenv("O3D_NO_BRICKS") ? 0 : 1;  // tuning aid
+  O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist, 1));
   O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
   const int apply_init = is_identity(init) ? 0 : 1;  // Registration.cpp:150-152
@@ -657,6 +658,14 @@ int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
   if (reset) O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * 8, ctx->stream));
   O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 8; i++) out[i] = t[i];
+  return O3D_OK;
+}
+
+int o3d_debug_grid_info(const o3d_ctx *ctx, double out[10]) {
+  if (!ctx || !out) return O3D_ERR_INVALID_ARG;
+  out[0] = ctx->gp.h; out[1] = ctx->gp.nx; out[2] = ctx->gp.ny; out[3] = ctx->gp.nz; out[4] = ctx->gp.nxp;
+  out[8] = ctx->gp.brick_bits ? (double)(1 << ctx->gp.brick_bits) : 0.0; out[9] = (double)ctx->n_bricks;
+  out[5] = ctx->gp.margin; out[6] = (ctx->tile_ok && ctx->use_tile && ctx->gp.margin) ? 1.0 : 0.0; out[7] = (double)ctx->n_tgt_grid;
   return O3D_OK;
 }
 

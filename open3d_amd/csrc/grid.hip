@@ -20,6 +20,10 @@ namespace {
 constexpr double kCellSlack = 1.0 + 1e-5;      // h = r * slack: covers float(r*r) round-up and floor() rounding
 constexpr uint64_t kMaxDenseCells = 1ull << 31;  // uint32 keys; dense table <= 8 GiB
 constexpr double kCellsPerPointBudget = 64.0;   // coarsen the grid when the dense table would dwarf the cloud
+constexpr int kMinBrickBits = 3, kMaxBrickBits = 6;  // bricks of 8^3 .. 64^3 cells
+constexpr uint64_t kMaxBrickDir = 1ull << 27;        // directory entries (one per brick of the bounding box): 512 MiB
+constexpr double kBrickEntriesPerPoint = 512.0;      // ... and the bricks' own budget: 2 KiB of table per point, 512 MiB at least
+constexpr double kMaxBrickAxis = 1048000.0;          // cells per axis (the fp32 prefilter wants cell indices below 2^20)
 
 struct Bounds6 {
   double mn[3], mx[3];
@@ -248,6 +252,107 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Bricked table (sparse scenes).  The dense table costs one entry per cell of the bounding box; a scene that is mostly
+// empty space -- clusters of surface far apart -- would need more cells than the budget allows, and coarser cells put
+// hundreds of points into each.  Here the cells keep the side max_dist and the table holds only bricks of B^3 cells that
+// some query can see a target point from (the cell of a point and its 26 neighbours).  A brick carries a halo -- (B+2) x
+// (B+2) rows of B+3 entries -- so that the rows and entries a query in one of its cells reads (cells cx-1 .. cx+1 and the
+// end of cx+1, rows cy-1 .. cy+1, cz-1 .. cz+1) lie inside it at fixed strides: the search kernels change in ONE place,
+// the address of the query's row (o3d_row_index: one more dependent load, the directory entry).  Every entry is what the
+// dense table would hold at that cell -- the number of target points whose row-major cell key is smaller -- so runs
+// along x stay contiguous in the cell-ordered target whatever brick they are read from.  Bricks nobody can see a point
+// from share one empty brick (all zero: every run empty).
+__global__ __launch_bounds__(O3D_BLOCK) void k_target_keys64(const double *__restrict__ xyz, int64_t n, GridParams gp,
+                                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint64_t key = ~0ull;  // non-finite points sort behind every cell
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+      int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+      int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+      key = ((uint64_t)cz * (uint64_t)gp.ny + (uint64_t)cy) * (uint64_t)gp.nxp + (uint64_t)(cx + 1);
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// One flag per brick that a query can see a point from: for the first point of every occupied cell, the bricks of the 27
+// cells around it.
+__global__ __launch_bounds__(O3D_BLOCK) void k_brick_mark(const uint64_t *__restrict__ keys, int64_t n_grid, GridParams gp,
+                                                           uint32_t *__restrict__ flags) {
+  for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const uint64_t key = keys[p];
+    if (p > 0 && keys[p - 1] == key) continue;
+    const int cx = (int)(key % (uint64_t)gp.nxp) - 1;
+    const uint64_t row = key / (uint64_t)gp.nxp;
+    const int cy = (int)(row % (uint64_t)gp.ny), cz = (int)(row / (uint64_t)gp.ny);
+    const int b = gp.brick_bits;
+    for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          const int qx = cx + dx, qy = cy + dy, qz = cz + dz;
+          if (qx < 0 || qx >= gp.nx || qy < 0 || qy >= gp.ny || qz < 0 || qz >= gp.nz) continue;
+          flags[((size_t)(qz >> b) * (size_t)gp.nby + (size_t)(qy >> b)) * (size_t)gp.nbx + (size_t)(qx >> b)] = 1u;
+        }
+  }
+}
+
+// flags + their exclusive scan -> the directory (first entry of the brick's table; brick 0 is the shared empty one) and
+// the list of the bricks that exist.
+__global__ __launch_bounds__(O3D_BLOCK) void k_brick_dir(uint32_t *__restrict__ flags_dir, const uint32_t *__restrict__ rank, int64_t ndir,
+                                                          uint32_t brick_entries, uint32_t *__restrict__ list) {
+  for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < ndir; i += (int64_t)gridDim.x * O3D_BLOCK) {
+    const uint32_t f = flags_dir[i];
+    if (f) {
+      const uint32_t r = rank[i];
+      list[r] = (uint32_t)i;
+      flags_dir[i] = (r + 1u) * brick_entries;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *__restrict__ keys, uint32_t lo, uint32_t hi, uint64_t target) {
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// The entries of the bricks that exist: one thread per row (two searches over all keys for the ends of the row's stretch
+// of B+3 cells, then a search inside that stretch -- usually empty -- per entry).
+__global__ __launch_bounds__(O3D_BLOCK) void k_brick_fill(const uint64_t *__restrict__ keys, uint32_t n_grid, GridParams gp,
+                                                           const uint32_t *__restrict__ list, int64_t n_bricks,
+                                                           uint32_t *__restrict__ table) {
+  const int b = gp.brick_bits, B = 1 << b, rows = (B + 2) * (B + 2), ne = B + 3;
+  const int64_t total = n_bricks * rows;
+  for (int64_t t = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; t < total; t += (int64_t)gridDim.x * O3D_BLOCK) {
+    const int64_t k = t / rows;
+    const int r = (int)(t - k * rows);
+    const uint32_t id = list[k];
+    const int bx = (int)(id % (uint32_t)gp.nbx), by = (int)((id / (uint32_t)gp.nbx) % (uint32_t)gp.nby),
+              bz = (int)(id / ((uint32_t)gp.nbx * (uint32_t)gp.nby));
+    const int gy = by * B + r % (B + 2) - 1, gz = bz * B + r / (B + 2) - 1;
+    uint32_t *__restrict__ out = table + (size_t)(k + 1) * (size_t)(rows * ne) + (size_t)r * ne;
+    if (gy < 0 || gy >= gp.ny || gz < 0 || gz >= gp.nz) {  // a row outside the grid: empty
+      for (int e = 0; e < ne; e++) out[e] = 0u;
+      continue;
+    }
+    const uint64_t k0 = ((uint64_t)gz * (uint64_t)gp.ny + (uint64_t)gy) * (uint64_t)gp.nxp + (uint64_t)(bx * B);
+    const uint32_t lo = lower_bound_u64(keys, 0u, n_grid, k0), hi = lower_bound_u64(keys, lo, n_grid, k0 + (uint64_t)(ne - 1));
+    out[0] = lo;
+    uint32_t at = lo;
+    for (int e = 1; e < ne - 1; e++) {
+      at = lower_bound_u64(keys, at, hi, k0 + (uint64_t)e);
+      out[e] = at;
+    }
+    out[ne - 1] = hi;
+  }
+}
+
 // Spread the low 21 bits of v so that bit i lands at bit 3*i.
 __device__ __forceinline__ uint64_t spread3(uint32_t v) {
   uint64_t x = v & 0x1fffffu;
@@ -348,9 +453,55 @@ int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], i
   return O3D_OK;
 }
 
-int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist) {
+// Cell size and table form for a target with bounding box bb: cells of side max_dist in a dense table when that fits the
+// budget; else, where the caller can read it, bricks (the smallest whose directory stays small); else coarser cells
+// (h *= 1.25 until the dense table fits -- still exact, only slower).
+static void choose_grid(const double bb[6], int64_t nfinite, double max_dist, bool bricks, GridParams &gp, uint64_t &ndir) {
+  double h = max_dist * kCellSlack;
+  const double ext[3] = {bb[3] - bb[0], bb[4] - bb[1], bb[5] - bb[2]};
+  const double budget = std::max(kCellsPerPointBudget * (double)nfinite, 16777216.0);
+  ndir = 0;
+  gp.brick_bits = 0;
+  for (bool first = true;; first = false) {
+    double c[3];
+    double total = 1.0;
+    // occupied cells per axis, plus a margin of empty cells: one either side in x, two either side in y and z.  A
+    // query in the outermost y / z layer, or outside the grid, is then at least one cell size (>= the radius) from
+    // every target point, and every other query has all 26 neighbour cells inside the table (no bounds checks).
+    for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0 + (d == 0 ? 2.0 : 4.0);
+    total = (c[0] + 2.0) * c[1] * c[2];
+    if (total < (double)kMaxDenseCells && total <= budget) {
+      gp.nx = (int)c[0]; gp.ny = (int)c[1]; gp.nz = (int)c[2];
+      break;
+    }
+    if (first && bricks && c[0] < kMaxBrickAxis && c[1] < kMaxBrickAxis && c[2] < kMaxBrickAxis) {
+      int b = kMinBrickBits;
+      for (; b <= kMaxBrickBits; b++) {
+        const double B = (double)(1 << b);
+        if ((floor(c[0] / B) + 1.0) * (floor(c[1] / B) + 1.0) * (floor(c[2] / B) + 1.0) <= (double)kMaxBrickDir) break;
+      }
+      if (b <= kMaxBrickBits) {
+        gp.nx = (int)c[0]; gp.ny = (int)c[1]; gp.nz = (int)c[2];
+        gp.brick_bits = b;
+        gp.nbx = (gp.nx >> b) + 1; gp.nby = (gp.ny >> b) + 1;
+        ndir = (uint64_t)gp.nbx * (uint64_t)gp.nby * (uint64_t)((gp.nz >> b) + 1);
+        break;
+      }
+    }
+    h *= 1.25;
+  }
+  gp.h = h;
+  gp.inv_h = 1.0 / h;
+  for (int d = 0; d < 3; d++) gp.gmin[d] = bb[d] - (d == 0 ? 1.0 : 2.0) * h;
+  gp.margin = 1;
+  gp.nxp = gp.nx + 2;
+  gp.ncell = gp.brick_bits ? 0u : (uint32_t)((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz);
+}
+
+int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist, int allow_bricks) {
   ctx->n_tgt = n;
   ctx->n_tgt_grid = 0;
+  ctx->n_bricks = 0;
   GridParams gp{};
   gp.nx = gp.ny = gp.nz = 1;
   gp.nxp = 3;
@@ -360,71 +511,100 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   double bb[6] = {0, 0, 0, 0, 0, 0};
   int64_t nfinite = 0;
   if (n > 0) O3D_TRY(o3d_bounds(ctx, dev_xyz, n, bb, &nfinite));
-  if (nfinite > 0) {
-    double h = max_dist * kCellSlack;
-    const double ext[3] = {bb[3] - bb[0], bb[4] - bb[1], bb[5] - bb[2]};
-    // Dense table budget: coarsen (h *= 1.25) until it fits; a coarser grid is still exact, only slower.
-    for (;;) {
-      double c[3];
-      double total = 1.0;
-      // occupied cells per axis, plus a margin of empty cells: one either side in x, two either side in y and z.  A
-      // query in the outermost y / z layer, or outside the grid, is then at least one cell size (>= the radius) from
-      // every target point, and every other query has all 26 neighbour cells inside the table (no bounds checks).
-      for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0 + (d == 0 ? 2.0 : 4.0);
-      total = (c[0] + 2.0) * c[1] * c[2];
-      const double budget = std::max(kCellsPerPointBudget * (double)nfinite, 16777216.0);
-      if (total < (double)kMaxDenseCells && total <= budget) {
-        gp.nx = (int)c[0]; gp.ny = (int)c[1]; gp.nz = (int)c[2];
-        break;
-      }
-      h *= 1.25;
-    }
-    gp.h = h;
-    gp.inv_h = 1.0 / h;
-    for (int d = 0; d < 3; d++) gp.gmin[d] = bb[d] - (d == 0 ? 1.0 : 2.0) * h;
-    gp.margin = 1;
-    gp.nxp = gp.nx + 2;
-    gp.ncell = (uint32_t)((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz);
-  }
-  ctx->gp = gp;
+  uint64_t ndir = 0;
+  if (nfinite > 0) choose_grid(bb, nfinite, max_dist, allow_bricks && ctx->use_bricks, gp, ndir);
   // the fp32 prefilter's error bound assumes fp64 cell origins are exact to well below fp32 resolution
   ctx->tile_ok = (gp.nx < (1 << 20) && gp.ny < (1 << 20) && gp.nz < (1 << 20)) ? 1 : 0;
 
-  // dense table: ncell + 1 prefix entries (+1 sentinel bucket for non-finite points), padded for uint4 access
-  const size_t ntab = (size_t)gp.ncell + 2;
-  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->cell_start, &ctx->cap_cells, sizeof(uint32_t) * (ntab + 8)));
-  if (n <= 0) {
-    O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (ntab + 8), ctx->stream));
-    return O3D_OK;
+  if (n > 0) {
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
+    // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
+    O3D_HIP(ctx, hipMemsetAsync(ctx->tgt_local + n, 0, sizeof(float4) * 4, ctx->stream));
+    if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
   }
-  O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start + ntab, 0, sizeof(uint32_t) * 8, ctx->stream));  // the padding entries
-
-  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
-  // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
-  O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
-  O3D_HIP(ctx, hipMemsetAsync(ctx->tgt_local + n, 0, sizeof(float4) * 4, ctx->stream));
-  if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
-
-  const size_t ntiles = o3d_sort_num_tiles(n);
+  const size_t ntiles = o3d_sort_num_tiles(n > 0 ? n : 1);
   const size_t nh = 256 * ntiles;
+  const int g = grid_for(n > 0 ? n : 1);
   void *keys, *vals, *tkeys, *tvals, *hist;
-  O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
-  O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
-  O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
-  O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
-  O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
 
-  const int g = grid_for(n);
-  hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint32_t *)keys,
-                     (uint32_t *)vals);
-  O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
-                             n, ceil_log2((uint64_t)gp.ncell + 1)));
-  if (ntab > (4u << 20))
-    hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
-                       (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
-  else
-    hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK), 0,
-                       ctx->stream, (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+  bool bricks_fit = true;
+  if (gp.brick_bits) {
+    const int B = 1 << gp.brick_bits;
+    const uint32_t brick_entries = (uint32_t)((B + 2) * (B + 2) * (B + 3));
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->brick_dir, &ctx->cap_dir, sizeof(uint32_t) * (size_t)ndir));
+    O3D_HIP(ctx, hipMemsetAsync(ctx->brick_dir, 0, sizeof(uint32_t) * (size_t)ndir, ctx->stream));
+    gp.dir = ctx->brick_dir;
+    O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint64_t) * (size_t)n, &keys));
+    O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
+    O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
+    O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    hipLaunchKernelGGL(k_target_keys64, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint64_t *)keys, (uint32_t *)vals);
+    O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, (uint32_t *)vals, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
+                               ceil_log2((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz + 1)));
+    hipLaunchKernelGGL(k_brick_mark, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys, nfinite, gp,
+                       ctx->brick_dir);
+    // rank of every brick that exists (a copy of the flags, scanned), and their number
+    void *rank, *bsums, *list;
+    O3D_TRY(o3d_scratch(ctx, 6, sizeof(uint32_t) * ((size_t)ndir + 1), &rank));
+    O3D_TRY(o3d_scratch(ctx, 7, sizeof(uint32_t) * (o3d_scan_num_blocks((int64_t)ndir + 1) + 8), &bsums));
+    O3D_HIP(ctx, hipMemcpyAsync(rank, ctx->brick_dir, sizeof(uint32_t) * (size_t)ndir, hipMemcpyDeviceToDevice, ctx->stream));
+    O3D_HIP(ctx, hipMemsetAsync((uint32_t *)rank + ndir, 0, sizeof(uint32_t), ctx->stream));
+    O3D_TRY(o3d_exclusive_scan_u32(ctx, (uint32_t *)rank, (uint32_t *)bsums, (int64_t)ndir + 1));
+    uint32_t *hcount = (uint32_t *)((char *)ctx->pinned + 512);
+    O3D_HIP(ctx, hipMemcpyAsync(hcount, (uint32_t *)rank + ndir, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n_bricks = (int64_t)*hcount;
+    // Points scattered thinly through the volume put nearly every point into a brick of its own: when the bricks would
+    // hold more entries than the budget, the scene is not locally dense either, and coarser cells in a dense table serve.
+    const double brick_budget = std::max(kBrickEntriesPerPoint * (double)nfinite, 134217728.0);
+    if ((double)(n_bricks + 1) * (double)brick_entries > brick_budget || (uint64_t)(n_bricks + 1) * (uint64_t)brick_entries >= (1ull << 32)) {
+      choose_grid(bb, nfinite, max_dist, false, gp, ndir);
+      gp.dir = nullptr;
+      ctx->tile_ok = (gp.nx < (1 << 20) && gp.ny < (1 << 20) && gp.nz < (1 << 20)) ? 1 : 0;
+      bricks_fit = false;
+    } else {
+    ctx->n_bricks = n_bricks;
+    O3D_TRY(o3d_scratch(ctx, 0, sizeof(uint32_t) * (size_t)(n_bricks + 1), &list));
+    const size_t ntab = (size_t)(n_bricks + 1) * (size_t)brick_entries;
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->cell_start, &ctx->cap_cells, sizeof(uint32_t) * (ntab + 8)));
+    O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (size_t)brick_entries, ctx->stream));  // the empty brick
+    O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start + ntab, 0, sizeof(uint32_t) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_brick_dir, dim3(grid_for((int64_t)ndir)), dim3(O3D_BLOCK), 0, ctx->stream, ctx->brick_dir, (const uint32_t *)rank,
+                       (int64_t)ndir, brick_entries, (uint32_t *)list);
+    if (n_bricks > 0)
+      hipLaunchKernelGGL(k_brick_fill, dim3(grid_for(n_bricks * (B + 2) * (B + 2))), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys,
+                         (uint32_t)nfinite, gp, (const uint32_t *)list, n_bricks, ctx->cell_start);
+    ctx->gp = gp;
+    }
+  }
+  if (!gp.brick_bits || !bricks_fit) {
+    ctx->gp = gp;
+    // dense table: ncell + 1 prefix entries (+1 sentinel bucket for non-finite points), padded for uint4 access
+    const size_t ntab = (size_t)gp.ncell + 2;
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->cell_start, &ctx->cap_cells, sizeof(uint32_t) * (ntab + 8)));
+    if (n <= 0) {
+      O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start, 0, sizeof(uint32_t) * (ntab + 8), ctx->stream));
+      return O3D_OK;
+    }
+    O3D_HIP(ctx, hipMemsetAsync(ctx->cell_start + ntab, 0, sizeof(uint32_t) * 8, ctx->stream));  // the padding entries
+    O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint32_t) * (size_t)n, &keys));
+    O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
+    O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
+    O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint32_t *)keys,
+                       (uint32_t *)vals);
+    O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
+                               n, ceil_log2((uint64_t)gp.ncell + 1)));
+    if (ntab > (4u << 20))
+      hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
+                         (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+    else
+      hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK), 0,
+                         ctx->stream, (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+  }
   ctx->n_tgt_grid = nfinite;
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,

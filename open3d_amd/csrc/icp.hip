@@ -76,9 +76,10 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
   const int cz = o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz);
   const bool inside = cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
   if (inside) {
-    const uint32_t rowc = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx;
+    const uint32_t rowc = o3d_row_index(gp, cx, cy, cz);
     const uint32_t s0 = cell_start[rowc], s1 = cell_start[rowc + 1], s2 = cell_start[rowc + 2], s3 = cell_start[rowc + 3];
-    // centre column of the eight neighbouring rows (rows outside the grid read a clamped, valid address)
+    // centre column of the eight neighbouring rows (dense table: rows outside the grid read a clamped, valid address;
+    // bricks: the halo holds them, empty)
     uint32_t rs1[8], rs2[8], rrow[8];
     {
       int k = 0;
@@ -88,7 +89,8 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
         for (int dy = -1; dy <= 1; dy++) {
           if (dz == 0 && dy == 0) continue;
           const int zz = min(max(cz + dz, 0), gp.nz - 1), yy = min(max(cy + dy, 0), gp.ny - 1);
-          rrow[k] = ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp + (uint32_t)cx;
+          rrow[k] = gp.brick_bits ? rowc + (uint32_t)(dy * o3d_row_stride_y(gp) + dz * o3d_row_stride_z(gp))
+                                  : ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp + (uint32_t)cx;
           rs1[k] = cell_start[rrow[k] + 1];
           rs2[k] = cell_start[rrow[k] + 2];
           k++;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void nn_search(const double4 *__restrict__ tgt, const
         }
       }
     }
-  } else {
+  } else if (!gp.brick_bits) {  // (a bricked table always has the margin: a query outside is a cell from every point)
     // query outside the target's bounding grid (or NaN): plain 27-cell search, x-neighbours as one run
     const int lo = max(cx - 1, -1), hi = min(cx + 1, gp.nx);
     if (lo <= hi) {
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   const float4 *__restrict__ tl = a.tgt_local;
   const uint32_t *__restrict__ cs = a.cell_start;
   const unsigned long long kBestInit = (unsigned long long)0x7F800000u << 32;  // +inf, position 0
-  const int row_y = gp.nxp, row_z = gp.ny * gp.nxp;  // table strides of one cell in y / z (wave-uniform)
+  const int row_y = o3d_row_stride_y(gp), row_z = o3d_row_stride_z(gp);  // table strides of one cell in y / z (wave-uniform)
 
   // The fp32 winner is confirmed in fp64 with the arithmetic of the exact search (it then IS the exact result: every
   // other candidate is farther by more than the fp32 error bound), and its terms of the next estimate go to the matrix
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
       qx = (float)((x - gp.gmin[0]) - (double)cx * gp.h);
       qy = (float)((y - gp.gmin[1]) - (double)cy * gp.h);
       qz = (float)((z - gp.gmin[2]) - (double)cz * gp.h);
-      rowp = cs + (((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx);
+      rowp = cs + o3d_row_index(gp, cx, cy, cz);
       const CellQuad qc = *reinterpret_cast<const CellQuad *>(rowp);
       s0 = qc.v[0]; s1 = qc.v[1]; s2 = qc.v[2]; s3 = qc.v[3];
     }

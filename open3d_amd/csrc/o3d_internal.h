@@ -35,6 +35,13 @@ struct GridParams {
   int nxp;         // padded row length = nx + 2 (one empty cell either side of every x-row)
   uint32_t ncell;  // nxp * ny * nz
   int margin;      // 1: the outer cell layers (1 in x, 2 in y and z) hold no target point (see o3d_build_target_grid)
+  // Sparse scenes (grid.hip, "bricks"): the table holds only the bricks of B^3 cells, B = 1 << brick_bits, that a query
+  // can see a target point from, each with a halo (B+2 rows in y and z, B+3 entries in x) so that the 3x3x3 block of any
+  // query routed to the brick lies inside it; dir[(bz * nby + by) * nbx + bx] is the brick's first entry (0: the shared
+  // empty brick).  brick_bits = 0: the dense table.
+  int brick_bits;
+  int nbx, nby;
+  const uint32_t *dir;
 };
 
 // Device-resident ICP state: everything the loop of Registration.cpp:146-167 carries between iterations.
@@ -76,6 +83,9 @@ struct o3d_ctx {
   int tile_stats = 0;             // collect g_tile_stats
   uint32_t *cell_start = nullptr; // ncell + 1 entries + pad
   size_t cap_tgt = 0, cap_nrm = 0, cap_cells = 0;
+  uint32_t *brick_dir = nullptr;  // GridParams::dir of a bricked table
+  size_t cap_dir = 0;
+  int64_t n_bricks = 0;
 
   // source shard
   int64_t n_src = 0;
@@ -110,6 +120,7 @@ struct o3d_ctx {
   int pass_grid = 0;    // workgroups of the accumulate / per-lane search kernels (one partial row each)
   int search_grid = 0;  // workgroups of k_icp_search_coop
   int use_seed = 1;     // k_icp_search_coop: previous match as the first pruning bound (O3D_NO_SEED=1 turns it off)
+  int use_bricks = 1;   // sparse scenes get the bricked cell table (O3D_NO_BRICKS=1: coarser cells in a dense table instead)
   int use_tail = 1;     // the search kernel's last workgroups end the pass (O3D_NO_TAIL=1: separate finalize / solve launch)
   int use_cert = 1;     // k_icp_search_coop: certified previous matches skip the search (O3D_NO_CERT=1 turns it off)
   double cert_gap = 0.0625;  // extra search reach for the certificates' slack, in cells (O3D_CERT_GAP)
@@ -183,7 +194,9 @@ size_t o3d_scan_num_blocks(int64_t n);
 int o3d_exclusive_scan_u32(o3d_ctx *ctx, uint32_t *data, uint32_t *block_sums, int64_t n);
 
 // ---- grid.hip -----------------------------------------------------------------
-int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist);
+// allow_bricks: a scene whose dense table of cells of side max_dist would exceed the budget gets the bricked table instead
+// of coarser cells (only the ICP search kernels read it; every other caller passes 0).
+int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist, int allow_bricks = 0);
 int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double *init_colmajor, int apply_init);
 // AABB over finite points: out6 (host) = {minx,miny,minz,maxx,maxy,maxz}; *out_finite = number of finite points.
 int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], int64_t *out_finite);
@@ -212,4 +225,20 @@ __device__ __forceinline__ int o3d_cell_coord(double x, double gmin, double inv_
   // monotone in x; NaN -> -2 (no neighbours); clamped to [-2, n+1]
   double f = floor((x - gmin) * inv_h);
   return (f >= -2.0) ? ((f <= (double)(n + 1)) ? (int)f : n + 1) : -2;
+}
+
+// Index into the cell table of the entry LEFT of cell (cx, cy, cz) -- the four entries from there are the starts of the
+// cells cx-1, cx, cx+1 and the end of cx+1 in the cell-ordered target -- for a cell inside the grid.  The rows (cy + dy,
+// cz + dz), |dy|, |dz| <= 1, are o3d_row_stride_y / _z entries away.
+__device__ __forceinline__ int o3d_row_stride_y(const GridParams &gp) { return gp.brick_bits ? (1 << gp.brick_bits) + 3 : gp.nxp; }
+__device__ __forceinline__ int o3d_row_stride_z(const GridParams &gp) {
+  return gp.brick_bits ? ((1 << gp.brick_bits) + 2) * ((1 << gp.brick_bits) + 3) : gp.ny * gp.nxp;
+}
+__device__ __forceinline__ uint32_t o3d_row_index(const GridParams &gp, int cx, int cy, int cz) {
+  if (gp.brick_bits) {
+    const int b = gp.brick_bits, m = (1 << b) - 1;
+    const uint32_t base = gp.dir[((uint32_t)(cz >> b) * (uint32_t)gp.nby + (uint32_t)(cy >> b)) * (uint32_t)gp.nbx + (uint32_t)(cx >> b)];
+    return base + (uint32_t)(((cz & m) + 1) * o3d_row_stride_z(gp) + ((cy & m) + 1) * o3d_row_stride_y(gp) + (cx & m));
+  }
+  return ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)cx;
 }

@@ -72,6 +72,10 @@ def test_coarsened_grid_still_exact(ctx, oracle):
     tgt = rng.random((20000, 3)) * 1000.0
     src = tgt[rng.integers(0, len(tgt), 5000)] + rng.normal(0, 0.01, (5000, 3))
     _check(ctx, oracle, src, tgt, 0.05)
+    # scattered this thinly, nearly every point would need a brick of its own: the bricked table (test_gpu_sparse.py) is
+    # tried, found larger than its budget, and the dense table with coarser cells is built instead
+    info = ctx.grid_info()
+    assert info["brick_side"] == 0 and info["cell_side"] > 1.0, info
 
 
 def test_surface_1m_matches_kdtree_oracle(ctx, oracle):
