@@ -1141,12 +1141,12 @@ __global__ __launch_bounds__(O3D_FIN_THREADS) void k_icp_finalize(const double *
 // ------------------------------------------------------------------ small dense algebra, one lane
 #define TM(T, r, c) ((T)[(c) * 4 + (r)])
 
-__device__ void mat4_identity(double *T) {
+__device__ __forceinline__ void mat4_identity(double *T) {
   for (int i = 0; i < 16; i++) T[i] = 0.0;
   T[0] = T[5] = T[10] = T[15] = 1.0;
 }
 
-__device__ void mat4_mul(const double *A, const double *B, double *C) {
+__device__ __forceinline__ void mat4_mul(const double *A, const double *B, double *C) {
   double R[16];
   for (int c = 0; c < 4; c++)
     for (int r = 0; r < 4; r++) {
@@ -1274,7 +1274,7 @@ __device__ void ldlt_solve6(const double *A, const double *b, double *x) {
 }
 #undef MR
 
-__device__ void vec6_to_mat4(const double *v, double *T) {
+__device__ __forceinline__ void vec6_to_mat4(const double *v, double *T) {
   double sx, cx, sy, cy, sz, cz;  // one argument reduction per angle
   sincos(v[0], &sx, &cx);
   sincos(v[1], &sy, &cy);
@@ -1286,87 +1286,114 @@ __device__ void vec6_to_mat4(const double *v, double *T) {
   TM(T, 0, 3) = v[3]; TM(T, 1, 3) = v[4]; TM(T, 2, 3) = v[5];
 }
 
-__device__ void cross3(const double *a, const double *b, double *c) {
+__device__ __forceinline__ void cross3(const double *a, const double *b, double *c) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
   c[2] = a[0] * b[1] - a[1] * b[0];
 }
-__device__ double det3(const double *M) {
+__device__ __forceinline__ double det3(const double *M) {
   return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
-// A = U diag(S) V^T (row-major 3x3), one-sided Jacobi; singular values descending.
-__device__ void svd3(const double *A, double *U, double *S, double *V) {
+// A = U diag(S) V^T (row-major 3x3), one-sided Jacobi; singular values descending.  Every index is static (the rotations
+// are instantiated per column pair, the ordering swaps whole columns by selects): the arrays stay in registers -- with
+// loop-variable indices they lived in scratch memory, a dependent memory access per element on the one lane that runs the
+// estimate (5 us of the 27 us of a 100 k-point point-to-point iteration).  The arithmetic is unchanged.
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&W)[9], double (&Vm)[9], double &off) {
+  double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    alpha += W[i * 3 + P] * W[i * 3 + P];
+    beta += W[i * 3 + Q] * W[i * 3 + Q];
+    gamma += W[i * 3 + P] * W[i * 3 + Q];
+  }
+  if (gamma == 0.0) return;
+  if (gamma * gamma <= 1e-32 * alpha * beta) return;
+  off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double wp = W[i * 3 + P], wq = W[i * 3 + Q];
+    W[i * 3 + P] = c * wp - sn * wq;
+    W[i * 3 + Q] = sn * wp + c * wq;
+    const double vp = Vm[i * 3 + P], vq = Vm[i * 3 + Q];
+    Vm[i * 3 + P] = c * vp - sn * vq;
+    Vm[i * 3 + Q] = sn * vp + c * vq;
+  }
+}
+
+// columns A and B of W and Vm and their singular values change places when sv[B] > sv[A]
+template <int A, int B>
+__device__ __forceinline__ void svd_order(double (&W)[9], double (&Vm)[9], double (&sv)[3]) {
+  const bool sw = sv[B] > sv[A];
+  double t;
+  t = sv[A]; sv[A] = sw ? sv[B] : t; sv[B] = sw ? t : sv[B];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t = W[i * 3 + A]; W[i * 3 + A] = sw ? W[i * 3 + B] : t; W[i * 3 + B] = sw ? t : W[i * 3 + B];
+    t = Vm[i * 3 + A]; Vm[i * 3 + A] = sw ? Vm[i * 3 + B] : t; Vm[i * 3 + B] = sw ? t : Vm[i * 3 + B];
+  }
+}
+
+__device__ __forceinline__ void svd3(const double *A, double *U, double *S, double *V) {
   double W[9], Vm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
   for (int i = 0; i < 9; i++) W[i] = A[i];
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++) {
-        double alpha = 0, beta = 0, gamma = 0;
-        for (int i = 0; i < 3; i++) {
-          alpha += W[i * 3 + p] * W[i * 3 + p];
-          beta += W[i * 3 + q] * W[i * 3 + q];
-          gamma += W[i * 3 + p] * W[i * 3 + q];
-        }
-        if (gamma == 0.0) continue;
-        if (gamma * gamma <= 1e-32 * alpha * beta) continue;
-        off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int i = 0; i < 3; i++) {
-          const double wp = W[i * 3 + p], wq = W[i * 3 + q];
-          W[i * 3 + p] = c * wp - s * wq;
-          W[i * 3 + q] = s * wp + c * wq;
-          const double vp = Vm[i * 3 + p], vq = Vm[i * 3 + q];
-          Vm[i * 3 + p] = c * vp - s * vq;
-          Vm[i * 3 + q] = s * vp + c * vq;
-        }
-      }
+    jacobi_rotate<0, 1>(W, Vm, off);
+    jacobi_rotate<0, 2>(W, Vm, off);
+    jacobi_rotate<1, 2>(W, Vm, off);
     if (off < 1e-15) break;
   }
   double sv[3];
+#pragma unroll
   for (int j = 0; j < 3; j++) sv[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
-  int ord[3] = {0, 1, 2};
-  for (int a = 0; a < 2; a++)
-    for (int b = a + 1; b < 3; b++)
-      if (sv[ord[b]] > sv[ord[a]]) { int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+  // the selection sort of the column order (largest first, a swap only on strictly greater), applied to the columns
+  svd_order<0, 1>(W, Vm, sv);
+  svd_order<0, 2>(W, Vm, sv);
+  svd_order<1, 2>(W, Vm, sv);
   double Uc[3][3];
-  int have[3] = {0, 0, 0};
+  bool have[3];
+#pragma unroll
   for (int j = 0; j < 3; j++) {
-    const int o = ord[j];
-    S[j] = sv[o];
-    for (int i = 0; i < 3; i++) V[i * 3 + j] = Vm[i * 3 + o];
-    if (sv[o] > 1e-300 && sv[o] > sv[ord[0]] * 1e-14) {
-      for (int i = 0; i < 3; i++) Uc[j][i] = W[i * 3 + o] / sv[o];
-      have[j] = 1;
-    }
+    S[j] = sv[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) V[i * 3 + j] = Vm[i * 3 + j];
+    have[j] = sv[j] > 1e-300 && sv[j] > sv[0] * 1e-14;
+#pragma unroll
+    for (int i = 0; i < 3; i++) Uc[j][i] = have[j] ? W[i * 3 + j] / sv[j] : 0.0;
   }
   if (!have[0]) { Uc[0][0] = 1; Uc[0][1] = 0; Uc[0][2] = 0; }
   if (!have[1]) {
-    double e[3] = {0, 0, 0};
     const double a0 = fabs(Uc[0][0]), a1 = fabs(Uc[0][1]), a2 = fabs(Uc[0][2]);
     const int m = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
-    e[m] = 1;
+    const double e[3] = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
     double c[3];
     cross3(Uc[0], e, c);
     const double nrm = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+#pragma unroll
     for (int i = 0; i < 3; i++) Uc[1][i] = c[i] / nrm;
   }
   if (!have[2]) {
     double c[3];
     cross3(Uc[0], Uc[1], c);
     const double nrm = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+#pragma unroll
     for (int i = 0; i < 3; i++) Uc[2][i] = c[i] / nrm;
   }
+#pragma unroll
   for (int j = 0; j < 3; j++)
+#pragma unroll
     for (int i = 0; i < 3; i++) U[i * 3 + j] = Uc[j][i];
 }
 
 // Eigen::umeyama from single-pass moments about a fixed origin c (TransformationEstimation.cpp:59):
 // mu_s = c + S_s/n, mu_d = c + S_d/n, sigma = S_ds/n - (S_d/n)(S_s/n)^T, var_s = S_ss/n - |S_s/n|^2.
-__device__ void umeyama_from_sums(const double *q, const double *centre, int with_scaling, double *T) {
+__device__ __forceinline__ void umeyama_from_sums(const double *q, const double *centre, int with_scaling, double *T) {
   const double n = q[O3D_SUM_NC];
   const double inv_n = 1.0 / n;
   double ms[3], md[3];
