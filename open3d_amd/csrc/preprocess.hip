@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
                                                                       const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
                                                                       double thr, double *normals, int has_normals, int by_pos,
                                                                       const double *ref, uint32_t *__restrict__ fb_list,
-                                                                      uint32_t *__restrict__ fb_count) {
+                                                                      uint32_t *__restrict__ fb_count, int knn_only) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary positions
@@ -660,7 +660,9 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
         n_in++;
       }
     });
-    bool fb = n_in >= 255;  // a byte counter may have saturated
+    // a byte counter may have saturated; KNN search (thr = the cell side squared, what the 3x3x3 block is guaranteed to
+    // cover): with fewer than k points that near, the k-th neighbour lies outside the block
+    bool fb = n_in >= 255 || (knn_only && n_in < knn);
     const int k_eff = min(knn, n_in);
     // prefix: slice of the k-th nearest, number of candidates below it, first list place of every slice
     int bstar = kHistBins, c_lo = 0;
@@ -1165,21 +1167,21 @@ static int count_occupied_cells(o3d_ctx *ctx, int64_t n, int64_t *out) {
 
 // Grid for k-nearest-neighbour queries over a cloud: cell size from the cloud's density, aiming at ~8 points per
 // occupied cell (at most four trial builds).  Leaves the grid built; *out_h is the cell size asked for last.
-static int build_knn_grid(o3d_ctx *ctx, const double *d_xyz, int64_t n, double *out_h) {
+static int build_knn_grid(o3d_ctx *ctx, const double *d_xyz, int64_t n, double *out_h, double want = 8.0, double at_least = 4.0) {
   double bb[6];
   int64_t nf = 0;
   O3D_TRY(o3d_bounds(ctx, d_xyz, n, bb, &nf));
   const double ext = std::max(std::max(bb[3] - bb[0], bb[4] - bb[1]), std::max(bb[5] - bb[2], 1e-300));
-  double h = ext * sqrt(8.0 / (double)std::max<int64_t>(nf, 1));
+  double h = ext * sqrt(want / (double)std::max<int64_t>(nf, 1));
   if (!(h > 0.0)) h = 1.0;
   for (int trial = 0; trial < 4 && nf > 0; trial++) {
     O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, h));
     int64_t occ = 0;
     O3D_TRY(count_occupied_cells(ctx, n, &occ));
     const double pop = (double)nf / (double)std::max<int64_t>(occ, 1);
-    if (pop >= 4.0 && pop <= 16.0) break;
-    if (ctx->gp.h > h * 1.01 && pop > 16.0) break;  // the dense-table budget already coarsened the grid
-    h = ctx->gp.h / (1.0 + 1e-5) * pow(8.0 / pop, 1.0 / 2.5);
+    if (pop >= at_least && pop <= 2.0 * want) break;
+    if (ctx->gp.h > h * 1.01 && pop > 2.0 * want) break;  // the dense-table budget already coarsened the grid
+    h = ctx->gp.h / (1.0 + 1e-5) * pow(want / pop, 1.0 / 2.5);
   }
   *out_h = h;
   return O3D_OK;
@@ -1223,7 +1225,13 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     if (search_type != O3D_SEARCH_RADIUS && knn > kMaxKnn)
       return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "EstimateNormals: knn/max_nn > %d is not on the device path", kMaxKnn);
     double h;
-    if (search_type == O3D_SEARCH_KNN) {
+    // KNN by counting (k_estimate_normals_hist): the 3x3x3 block is guaranteed to hold everything nearer than one cell side,
+    // so the cells are sized for the k nearest of a typical point to lie that near -- on a surface a disc of radius h holds
+    // pi times a cell's population -- and the points whose k-th neighbour is farther go to the heap kernel's shell walk
+    const bool knn_hist = search_type == O3D_SEARCH_KNN && knn >= 3 && knn <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP");
+    if (knn_hist) {
+      O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h, std::max(8.0, 0.6 * knn), std::max(4.0, 0.45 * knn)));
+    } else if (search_type == O3D_SEARCH_KNN) {
       O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h));
     } else {
       h = radius;
@@ -1258,6 +1266,20 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
                            ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+      } else if (knn_hist) {
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
+        uint32_t *fb_list = (uint32_t *)sf + 64, *fb_count = (uint32_t *)sf;
+        O3D_HIP(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), ctx->stream));
+        const double reach = ctx->gp.h / (1.0 + 1e-5);  // (the grid was built for this "radius": cell side = reach * slack)
+        const double thr_knn = (double)(float)(reach * reach);
+        const size_t hlds = hist_lds_bytes(kk);
+        O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
+        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr_knn, d_out, has_normals, by_pos, ref, fb_list, fb_count, 1);
+        O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
+        hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 4)), dim3(kNrmBlock), lds, ctx->stream,
+                           ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,
+                           (const uint32_t *)fb_list, (const uint32_t *)fb_count);
       } else if (search_type == O3D_SEARCH_KNN) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
@@ -1274,7 +1296,7 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         const size_t hlds = hist_lds_bytes(kk);
         O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
         hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count, 0);
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 2)), dim3(kNrmBlock), lds, ctx->stream,
                            ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,

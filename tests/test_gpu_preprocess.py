@@ -309,3 +309,27 @@ def test_estimate_normals_shards_reassemble_bit_identically(ctx, mode):
             # the last shard's call left the grid in the context: assemble follows directly
             got = eng.assemble(pts, np.concatenate(parts), G)
             assert np.array_equal(got, whole.normals_), (mode, G)
+
+
+@pytest.mark.parametrize("k", [3, 12, 30, 64])
+def test_knn_normals_by_counting_equal_the_heap_kernel(ctx, monkeypatch, k):
+    """KNN search (the reference's default, KDTreeSearchParamKNN(30)) through the counting kernel -- cells sized so that the
+    k nearest usually lie within one cell side, everything else handed to the heap kernel's shell walk -- against the heap
+    kernel alone (O3D_NORMALS_HEAP=1): bit-identical, on a surface with a hole and an edge, a volume, a dense blob with far
+    outliers (their k-th neighbour is many cells away) and a cloud of fewer than k points."""
+    geometry = _geo()
+    rng = np.random.default_rng(40 + k)
+    sc = make_scene(60_000, 60_000, cfg_id=12)
+    surf = sc["target"]
+    surf = surf[np.linalg.norm(surf[:, :2] - surf[:, :2].mean(0), axis=1) > 0.7]          # a hole
+    clouds = [surf, rng.random((30_000, 3)),
+              np.concatenate([rng.random((5000, 3)), rng.random((40, 3)) * 80.0 + 10.0]), rng.random((k - 1, 3))]
+    for pts in clouds:
+        got = geometry.PointCloud(pts)
+        monkeypatch.delenv("O3D_NORMALS_HEAP", raising=False)
+        got.EstimateNormals(geometry.KDTreeSearchParamKNN(k), ctx=ctx)
+        want = geometry.PointCloud(pts)
+        monkeypatch.setenv("O3D_NORMALS_HEAP", "1")
+        want.EstimateNormals(geometry.KDTreeSearchParamKNN(k), ctx=ctx)
+        monkeypatch.delenv("O3D_NORMALS_HEAP", raising=False)
+        assert np.array_equal(got.normals_, want.normals_)
