@@ -495,7 +495,6 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     ctx->slg = sqrt(lambda_geometric);
     ctx->slp = sqrt(1.0 - lambda_geometric);
   }
-  ctx->use_bricks = getenv("O3D_NO_BRICKS") ? 0 : 1;  // tuning aid
   O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist, 1));
   O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 

@@ -512,6 +512,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   int64_t nfinite = 0;
   if (n > 0) O3D_TRY(o3d_bounds(ctx, dev_xyz, n, bb, &nfinite));
   uint64_t ndir = 0;
+  ctx->use_bricks = getenv("O3D_NO_BRICKS") ? 0 : 1;  // tuning aid
   if (nfinite > 0) choose_grid(bb, nfinite, max_dist, allow_bricks && ctx->use_bricks, gp, ndir);
   // the fp32 prefilter's error bound assumes fp64 cell origins are exact to well below fp32 resolution
   ctx->tile_ok = (gp.nx < (1 << 20) && gp.ny < (1 << 20) && gp.nz < (1 << 20)) ? 1 : 0;

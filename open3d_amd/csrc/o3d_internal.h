@@ -86,6 +86,7 @@ struct o3d_ctx {
   uint32_t *brick_dir = nullptr;  // GridParams::dir of a bricked table
   size_t cap_dir = 0;
   int64_t n_bricks = 0;
+  double knn_grid_h = -1.0;  // build_knn_grid: the cell size its last trial build was made for
 
   // source shard
   int64_t n_src = 0;

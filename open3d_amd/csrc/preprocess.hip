@@ -367,10 +367,23 @@ __device__ __forceinline__ void klist_sort(KList &l) {
 // kNrmLoads candidates in flight at a time across row ends -- at ~1 wavefront per SIMD every dependent round trip is
 // exposed, and row by row there were two per row (bounds, candidates) plus one per further kNrmLoads candidates.
 // visit(point, position, real): real = 0 marks a padding slot of the last batch (`pad` is any valid position).
-template <typename F>
-__device__ __forceinline__ void walk_block3(const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
-                                            const GridParams &gp, int cx, int cy, int cz, uint32_t pad, F &&visit) {
-  uint32_t rs[9], re[9];
+// The nine runs (dz outer, dy inner) of the 3x3x3 block around cell (cx, cy, cz) in the cell-ordered cloud.  Bricked
+// table (sparse scenes, grid.hip): the rows of a cell inside the grid lie in its brick at fixed strides; a cell outside
+// the grid is a cell side from every point (the margin) and sees nothing.
+__device__ __forceinline__ void block3_bounds(const uint32_t *__restrict__ cell_start, const GridParams &gp, int cx, int cy, int cz,
+                                              uint32_t (&rs)[9], uint32_t (&re)[9]) {
+  if (gp.brick_bits) {
+    const bool inside = cx >= 0 && cx < gp.nx && cy >= 0 && cy < gp.ny && cz >= 0 && cz < gp.nz;
+    const uint32_t rowc = inside ? o3d_row_index(gp, cx, cy, cz) : 0u;
+    const int sy = o3d_row_stride_y(gp), sz = o3d_row_stride_z(gp);
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      const uint32_t at = rowc + (uint32_t)((r % 3 - 1) * sy + (r / 3 - 1) * sz);
+      rs[r] = inside ? cell_start[at] : 0u;
+      re[r] = inside ? cell_start[at + 3] : 0u;
+    }
+    return;
+  }
   const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
 #pragma unroll
   for (int r = 0; r < 9; r++) {
@@ -381,6 +394,13 @@ __device__ __forceinline__ void walk_block3(const double4 *__restrict__ pts, con
     rs[r] = ok ? s0 : 0u;
     re[r] = ok ? e0 : 0u;
   }
+}
+
+template <typename F>
+__device__ __forceinline__ void walk_block3(const double4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                            const GridParams &gp, int cx, int cy, int cz, uint32_t pad, F &&visit) {
+  uint32_t rs[9], re[9];
+  block3_bounds(cell_start, gp, cx, cy, cz, rs, re);
   int r = 0;
   uint32_t j = rs[0], e = re[0];
   auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
@@ -633,18 +653,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
     const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
     l.qx = q.x; l.qy = q.y; l.qz = q.z;
     uint32_t rs[9], re[9];
-    {
-      const int xa = max(cx - 1, -1), xb = min(cx + 1, gp.nx);
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
-        const bool ok = zz >= 0 && zz < gp.nz && yy >= 0 && yy < gp.ny;
-        const uint32_t row = ok ? ((uint32_t)zz * (uint32_t)gp.ny + (uint32_t)yy) * (uint32_t)gp.nxp : 0u;
-        const uint32_t s0 = cell_start[row + (uint32_t)(xa + 1)], e0 = cell_start[row + (uint32_t)(xb + 2)];
-        rs[r] = ok ? s0 : 0u;
-        re[r] = ok ? e0 : 0u;
-      }
-    }
+    block3_bounds(cell_start, gp, cx, cy, cz, rs, re);
 #pragma unroll
     for (int w = 0; w < kHistBins / 4; w++) hist[w * kNrmBlock] = 0u;
     // walk 1: count
@@ -1176,6 +1185,7 @@ static int build_knn_grid(o3d_ctx *ctx, const double *d_xyz, int64_t n, double *
   if (!(h > 0.0)) h = 1.0;
   for (int trial = 0; trial < 4 && nf > 0; trial++) {
     O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, h));
+    ctx->knn_grid_h = h;  // what the grid in the context was built for
     int64_t occ = 0;
     O3D_TRY(count_occupied_cells(ctx, n, &occ));
     const double pop = (double)nf / (double)std::max<int64_t>(occ, 1);
@@ -1228,6 +1238,7 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     // KNN by counting (k_estimate_normals_hist): the 3x3x3 block is guaranteed to hold everything nearer than one cell side,
     // so the cells are sized for the k nearest of a typical point to lie that near -- on a surface a disc of radius h holds
     // pi times a cell's population -- and the points whose k-th neighbour is farther go to the heap kernel's shell walk
+    ctx->knn_grid_h = -1.0;
     const bool knn_hist = search_type == O3D_SEARCH_KNN && knn >= 3 && knn <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP");
     if (knn_hist) {
       O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h, std::max(8.0, 0.6 * knn), std::max(4.0, 0.45 * knn)));
@@ -1238,7 +1249,9 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     }
     // degenerate: knn < 3 or an empty radius -- no point can collect 3 neighbours, every normal becomes (0, 0, 1)
     // (:347-349); run the hybrid kernel with an empty acceptance threshold
-    O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, degenerate ? 1.0 : h));
+    // (radius and hybrid searches read the 3x3x3 block only: they can use the bricked table of a sparse scene)
+    if (!(search_type == O3D_SEARCH_KNN && !degenerate && ctx->knn_grid_h == h && ctx->n_tgt == n))  // (the trial build already is it)
+      O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, degenerate ? 1.0 : h, search_type != O3D_SEARCH_KNN && !degenerate));
     const int64_t ng = ctx->n_tgt_grid;
     if (out_ng) *out_ng = ng;
     int64_t p_lo = 0, p_hi = ng, rows = 0;
@@ -1494,7 +1507,7 @@ int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_n
   ctx->icp_ready = 0;
   O3D_HIP(ctx, hipMemsetAsync(d_grad, 0, sizeof(double) * 3 * (size_t)n, ctx->stream));
   if (!(radius > 0.0) || max_nn < 4) return O3D_OK;  // no point can collect 4 neighbours
-  O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius));
+  O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius, 1));
   const int64_t ng = ctx->n_tgt_grid;
   if (ng <= 0) return O3D_OK;
   const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:148
@@ -1548,7 +1561,7 @@ int o3d_neighbor_query_impl(o3d_ctx *ctx, int mode, const double *cloud_xyz, int
       d_out = so;
     }
     double h = radius;
-    if (mode == 2) O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, n_cloud, radius));
+    if (mode == 2) O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, n_cloud, radius, 1));
     else if (n_cloud > 0) O3D_TRY(build_knn_grid(ctx, d_cloud, n_cloud, &h));
     else O3D_TRY(o3d_build_target_grid(ctx, d_cloud, nullptr, 0, 1.0));
     const int kk = (mode == 2) ? 1 : knn;
@@ -1619,7 +1632,7 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
     }
     double h = radius;
     if (knn_mode) O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h));
-    else O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius));
+    else O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius, 1));
     const int64_t ng = ctx->n_tgt_grid;
     if (ng > 0) {
       const double thr = (double)(float)(radius * radius);

@@ -106,3 +106,47 @@ def test_bricked_table_points_on_brick_faces(ctx, oracle):
     assert ctx.grid_info()["brick_side"] >= 8
     ref = oracle.registration_icp(src, tgt, r, None, 1, None, rel_fitness=0.0, rel_rmse=0.0, max_iter=2)
     assert np.array_equal(res.corr_, ref.corr) and rel_err(res.transformation_, ref.transformation) < 1e-6
+
+
+def test_bricked_table_under_normals_and_neighbour_queries(ctx, oracle):
+    """The radius / hybrid searches of the preprocessing entry points read the 3x3x3 block only and use the bricked table of
+    a sparse scene too: EstimateNormals (hybrid, by counting; radius, by heaps), ComputePointCloudDistance's companion
+    counts (RemoveRadiusOutliers) and FPFH (hybrid) against the oracle, and against the dense table with coarser cells."""
+    from open3d_amd import geometry
+    sc = cluster_scene(40_000, 2500.0, 10, 1.2, seed=9)
+    pts, s = sc["target"], sc["spacing"]
+    for sp, args in ((geometry.KDTreeSearchParamHybrid(4 * s, 30), (oracle.HYBRID, 30, 4 * s)),
+                     (geometry.KDTreeSearchParamRadius(2.5 * s), (oracle.RADIUS, 0, 2.5 * s))):
+        pc = geometry.PointCloud(pts)
+        pc.EstimateNormals(sp, ctx=ctx)
+        assert ctx.grid_info()["brick_side"] >= 8, ctx.grid_info()
+        ref = oracle.estimate_normals(pts, *args)
+        # hybrid: the neighbours are summed in (distance, index) order everywhere.  Radius: in the order they are met, which
+        # depends on the cell layout, and the covariance comes from cumulants about the origin (EstimateNormals.cpp:222-244)
+        # of coordinates up to 2500 m -- sixteen digits minus nine of cancellation
+        hybrid = args[0] == oracle.HYBRID
+        ok = np.abs(pc.normals_ - ref).max(axis=1) < (1e-9 if hybrid else 1e-4)
+        assert ok.mean() > 0.9999
+        os.environ["O3D_NO_BRICKS"] = "1"
+        try:
+            dense = geometry.PointCloud(pts)
+            dense.EstimateNormals(sp, ctx=ctx)
+            assert ctx.grid_info()["brick_side"] == 0
+        finally:
+            os.environ.pop("O3D_NO_BRICKS", None)
+        if hybrid:
+            assert np.array_equal(dense.normals_, pc.normals_)
+        else:
+            assert (np.abs(dense.normals_ - pc.normals_).max(axis=1) < 1e-4).mean() > 0.9999
+    # radius neighbour counts (RemoveRadiusOutliers, PointCloud.cpp:406-411)
+    pc = geometry.PointCloud(pts)
+    kept, idx = pc.RemoveRadiusOutliers(12, 3 * s, ctx=ctx)
+    assert ctx.grid_info()["brick_side"] >= 8
+    cnt = oracle.neighbor_query(2, pts, pts, radius=3 * s)
+    assert np.array_equal(np.asarray(idx), np.nonzero(np.asarray(cnt) > 12)[0])
+    os.environ["O3D_NO_BRICKS"] = "1"
+    try:
+        kept2, idx2 = geometry.PointCloud(pts).RemoveRadiusOutliers(12, 3 * s, ctx=ctx)
+    finally:
+        os.environ.pop("O3D_NO_BRICKS", None)
+    assert np.array_equal(np.asarray(idx), np.asarray(idx2)) and 0 < len(idx) < len(pts)
