@@ -565,6 +565,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   hs->radius = sqrt(diag2);
   // certificates hold while a query moves less than about half the slack its bound was given (the search's extra reach)
   hs->cert_skip_above = 0.5 * ctx->cert_gap * ctx->gp.h;
+  hs->seed_skip_above = 0.25 * ctx->gp.h;
   // (the staging page is rewritten by the next set-up on this context at the earliest, and every path to it --
   // o3d_icp_finish, o3d_icp_poll, o3d_icp_fetch, an error -- has synchronised the stream by then)
   O3D_HIP(ctx, o3d_h2d(ctx, ctx->state, hs, sizeof(IcpState)));

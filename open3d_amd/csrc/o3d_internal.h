@@ -54,6 +54,7 @@ struct IcpState {
   double n_src_global;
   double radius;            // half diagonal of the target's bounding box about `centre`
   double cert_skip_above;   // a pending update that moves the cloud farther than this makes k_icp_cert stand aside
+  double seed_skip_above;   // ... and farther than this, the previous matches are poor first bounds for the search
   int max_iter;
   int passes;        // LOOP-A passes completed
   int iters;         // estimation updates applied
@@ -62,6 +63,8 @@ struct IcpState {
   int estimation;
   int with_scaling;
   int skip_cert;     // the pending update is too large for the certificates (k_icp_cert returns at once, everything is searched)
+  int skip_seed;     // ... and for the previous matches to seed the search
+  int pad_;
 };
 
 struct o3d_ctx {
