@@ -843,12 +843,13 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
       certified = has_prev ? (float)d2 * (1.0f + 1e-6f) < lb2   // m is strictly nearer than everything else
                            : lb2 > thrf * (1.0f + 1e-6f);        // nothing within the radius
     }
-    // m is the nearest point whatever its distance: beyond the radius it simply is no correspondence (Registration.cpp:64-66)
-    const bool use = certified && has_prev && d2 < a.thr;
-    if (certified) {
-      a.corr[i] = use ? (int32_t)__double_as_longlong(p.w) : O3D_CORR_NONE;
-      a.lb[i] = lbc;
-    }
+    // A certified query keeps its correspondence entry as it is -- the entry already names m (or nothing, without a match):
+    // the search that found m wrote it, and no later pass touched it -- so the entry is not rewritten here (4 of the 124
+    // bytes a certified point costs).  The one case that would change it, m still the nearest point but now beyond the
+    // radius (no correspondence, Registration.cpp:64-66), is left to the search, which clears entry and match together.
+    if (certified && has_prev && !(d2 < a.thr)) certified = false;
+    const bool use = certified && has_prev;
+    if (certified) a.lb[i] = lbc;
     const unsigned long long need = __ballot(valid && !certified);
     if (valid && !certified) a.work[wr.beg + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
     nwork += (uint32_t)__popcll(need);
