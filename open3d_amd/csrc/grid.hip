@@ -224,7 +224,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__restrict__ xyz, const double *__restrict__ nrm,
                                                               const uint32_t *__restrict__ vals, int64_t n_grid, GridParams gp,
                                                               double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted,
-                                                              float4 *__restrict__ tgt_local) {
+                                                              float4 *__restrict__ tgt_local, double4 *__restrict__ tn_sorted) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const uint32_t i = vals[p];
     double4 q;
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
       nrm_sorted[3 * p] = nrm[3 * (size_t)i];
       nrm_sorted[3 * p + 1] = nrm[3 * (size_t)i + 1];
       nrm_sorted[3 * p + 2] = nrm[3 * (size_t)i + 2];
+      if (tn_sorted) {
+        tn_sorted[2 * p] = q;
+        tn_sorted[2 * p + 1] = make_double4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], 0.0);
+      }
     }
   }
 }
@@ -502,6 +506,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   ctx->n_tgt = n;
   ctx->n_tgt_grid = 0;
   ctx->n_bricks = 0;
+  ctx->tn_valid = 0;
   GridParams gp{};
   gp.nx = gp.ny = gp.nz = 1;
   gp.nxp = 3;
@@ -517,12 +522,15 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   // the fp32 prefilter's error bound assumes fp64 cell origins are exact to well below fp32 resolution
   ctx->tile_ok = (gp.nx < (1 << 20) && gp.ny < (1 << 20) && gp.nz < (1 << 20)) ? 1 : 0;
 
+  bool want_tn = false;
   if (n > 0) {
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
     // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
     O3D_HIP(ctx, hipMemsetAsync(ctx->tgt_local + n, 0, sizeof(float4) * 4, ctx->stream));
     if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
+    want_tn = dev_nrm && allow_bricks && !getenv("O3D_NO_TN");  // (the ICP set-up; the switch is a tuning aid)
+    if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double4) * 2 * (size_t)n));
   }
   const size_t ntiles = o3d_sort_num_tiles(n > 0 ? n : 1);
   const size_t nh = 256 * ntiles;
@@ -610,7 +618,8 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
                        (const uint32_t *)vals, nfinite, gp, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr,
-                       ctx->tgt_local);
+                       ctx->tgt_local, want_tn ? ctx->tn_sorted : nullptr);
+  ctx->tn_valid = (want_tn && nfinite > 0) ? 1 : 0;
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

@@ -281,6 +281,7 @@ struct PassArgs {
   const double4 *tgt;
   const float4 *tgt_local;
   const double *nrm;
+  const double4 *tn;     // point and normal side by side (two double4 per sorted target point), or null
   const uint32_t *cell_start;
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, or -1 none
@@ -815,9 +816,15 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
     double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
     double n0 = 0.0, n1 = 0.0, n2 = 0.0, is = 0.0;
     if (has_prev) {
-      p = a.tgt[pprev];
-      if (EST != O3D_EST_POINT_TO_POINT) {
-        n0 = a.nrm[3 * (size_t)pprev]; n1 = a.nrm[3 * (size_t)pprev + 1]; n2 = a.nrm[3 * (size_t)pprev + 2];
+      if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one aligned 64-byte record instead of two gathers
+        p = a.tn[2 * (size_t)pprev];
+        const double4 nn = a.tn[2 * (size_t)pprev + 1];
+        n0 = nn.x; n1 = nn.y; n2 = nn.z;
+      } else {
+        p = a.tgt[pprev];
+        if (EST != O3D_EST_POINT_TO_POINT) {
+          n0 = a.nrm[3 * (size_t)pprev]; n1 = a.nrm[3 * (size_t)pprev + 1]; n2 = a.nrm[3 * (size_t)pprev + 2];
+        }
       }
       if (EST == O3D_EST_COLORED_ICP) { tc = a.tcol[pprev]; is = a.sint[i]; }
     }
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
 // (already moved by the pending update), unless IcpState::skip_cert says that k_icp_cert stood aside.
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
-template <int EST>
+template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
   if (a.st->done) return;
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
@@ -878,7 +885,6 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   const double cx0 = uniform_f64(a.st->centre[0]), cy0 = uniform_f64(a.st->centre[1]), cz0 = uniform_f64(a.st->centre[2]);
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
   const bool listed = a.listed && !a.st->skip_cert;
-  const bool seed_on = a.seed && !a.st->skip_seed;
   const int apply = listed ? 0 : a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
@@ -888,7 +894,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
   const float margin = 1e-5f * hf;
-  const float seed_max = kSeedMax * hf * hf;
+  // (no seeds at all after a large step, IcpState::skip_seed: folded into the threshold, which costs no register)
+  const float seed_max = (a.seed && !a.st->skip_seed) ? kSeedMax * hf * hf : -1.0f;
   const float cap = hf * (1.0f - 1e-6f);  // every point outside the 3x3x3 block, or around a query outside the grid interior
   const float capsq = cap * cap;
   const float4 *__restrict__ tl = a.tgt_local;
@@ -934,7 +941,7 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     uint32_t pprev = O3D_POS_NONE;
     if (valid) {
       x = a.src_in[3 * i]; y = a.src_in[3 * i + 1]; z = a.src_in[3 * i + 2];
-      if (seed_on) pprev = a.pos[i];
+      if (seed_max > 0.f) pprev = a.pos[i];
     }
     if (valid && apply) {
       apply_update(T, w, x, y, z);
@@ -1065,9 +1072,15 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
     i_p = i;
     xs = x; ys = y; zs = z;
     if (use_p) {
-      p_p = a.tgt[bpos];
-      if (EST != O3D_EST_POINT_TO_POINT) {
-        n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
+      if (TN) {  // (never with point-to-point: no normals)
+        p_p = a.tn[2 * (size_t)bpos];
+        const double4 nn = a.tn[2 * (size_t)bpos + 1];
+        n0_p = nn.x; n1_p = nn.y; n2_p = nn.z;
+      } else {
+        p_p = a.tgt[bpos];
+        if (EST != O3D_EST_POINT_TO_POINT) {
+          n0_p = a.nrm[3 * (size_t)bpos]; n1_p = a.nrm[3 * (size_t)bpos + 1]; n2_p = a.nrm[3 * (size_t)bpos + 2];
+        }
       }
       if (EST == O3D_EST_COLORED_ICP) { tc_p = a.tcol[bpos]; is_p = a.sint[i]; }
     }
@@ -2044,6 +2057,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.stats = ctx->tile_stats;
   pa.ctr = ctx->counters;
   pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
+  pa.tn = ctx->tn_valid ? ctx->tn_sorted : nullptr;
   pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
@@ -2090,7 +2104,17 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
   if (fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
-    O3D_LAUNCH_EST(k_icp_search_coop, grows, pa, ctx->gp);
+    // (two instantiations rather than a run-time branch: with both gathers compiled in, the kernel spilled six registers)
+    if (pa.tn && est == O3D_EST_POINT_TO_PLANE)
+      hipLaunchKernelGGL((k_icp_search_coop<O3D_EST_POINT_TO_PLANE, true>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (pa.tn && est == O3D_EST_COLORED_ICP)
+      hipLaunchKernelGGL((k_icp_search_coop<O3D_EST_COLORED_ICP, true>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (est == O3D_EST_POINT_TO_PLANE)
+      hipLaunchKernelGGL((k_icp_search_coop<O3D_EST_POINT_TO_PLANE, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (est == O3D_EST_COLORED_ICP)
+      hipLaunchKernelGGL((k_icp_search_coop<O3D_EST_COLORED_ICP, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else
+      hipLaunchKernelGGL((k_icp_search_coop<O3D_EST_POINT_TO_POINT, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
   } else {
     hipLaunchKernelGGL(k_icp_search, dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
