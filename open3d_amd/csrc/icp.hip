@@ -782,7 +782,7 @@ __device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len) 
 }
 
 template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
+__device__ __forceinline__ void cert_body(const PassArgs &a) {
   if (a.st->done) return;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
   static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
@@ -871,12 +871,28 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
 }
 
+// The arguments of a pass's kernels as they sit in device memory for the graph form of the loop (o3d_graph_passes): a
+// graph whose kernel nodes take a pointer is instantiated once per context and serves every registration after it.
+struct PassLaunch {
+  PassArgs a;
+  GridParams gp;
+};
+
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
+  cert_body<EST>(a);
+}
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_ind(const PassLaunch *__restrict__ pl) {
+  cert_body<EST>(pl->a);
+}
+
 // The cooperative search (see above CoopWave).  PassArgs::listed: the queries are the work list k_icp_cert left behind
 // (already moved by the pending update), unless IcpState::skip_cert says that k_icp_cert stood aside.
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
 template <int EST, bool TN>
-__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
+__device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridParams &gp) {
   if (a.st->done) return;
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
   static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
@@ -1112,6 +1128,15 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
   __syncthreads();
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
   pass_tail(a, reinterpret_cast<double *>(wls), wr.chunk);
+}
+
+template <int EST, bool TN>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
+  search_coop_body<EST, TN>(a, gp);
+}
+template <int EST, bool TN>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_ind(const PassLaunch *__restrict__ pl) {
+  search_coop_body<EST, TN>(pl->a, pl->gp);
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -2046,14 +2071,18 @@ int o3d_launch_set_update(o3d_ctx *ctx, const double update[16]) {
   return O3D_OK;
 }
 
-int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
-  const bool prof = ctx->prof_on && ctx->prof_n < 340;
-  if (prof) {  // three events per pass: before the search kernel, after it, after the accumulation kernel (alternative path)
-    for (int k = 0; k < 3; k++)
-      if (!ctx->prof_ev[3 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[3 * ctx->prof_n + k]));
-    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n], ctx->stream));
-  }
+// The arguments of one pass.  listed_pass: a pass behind the first (certificates, where they are in use).
+struct PassPlan {
   PassArgs pa;
+  int grows;    // workgroups of the pass kernels
+  bool fused;   // k_icp_search_coop (else k_icp_search + k_icp_accumulate_mfma)
+  bool tail;    // the search kernel ends the pass itself
+  int nparts;
+};
+
+static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bool listed_pass) {
+  PassPlan pl;
+  PassArgs &pa = pl.pa;
   pa.stats = ctx->tile_stats;
   pa.ctr = ctx->counters;
   pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
@@ -2065,6 +2094,42 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
   pa.lb = ctx->lb_sorted;
   pa.work = ctx->work; pa.work_count = ctx->work_count;
   pa.tcol = ctx->tcol_sorted; pa.sint = ctx->sint_sorted; pa.slg = ctx->slg; pa.slp = ctx->slp;
+  // Default: ONE kernel per pass -- the cooperative fp32-prefilter search with the exact fp64 resolution of what fp32
+  // cannot decide and the estimate's sums fused in.  Alternative (grids too large for the fp32 error bound, or forced by
+  // o3d_debug_set): the per-lane fp64 search followed by the accumulation kernel.  One partial row per workgroup.
+  pl.fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
+  pl.grows = pl.fused ? ctx->search_grid : ctx->pass_grid;
+  // Certificates: the bounds refer to the position of the previous pass -- not in hypothesis mode, where every pass starts
+  // from the untouched source, and not in the first pass, which has nothing to certify.  The work list is laid out for the
+  // search kernel's chunks, so k_icp_cert runs on the same grid.
+  const bool cert = pl.fused && ctx->use_cert && !ctx->hyp_mode;
+  pa.gap = cert ? (float)(ctx->cert_gap * ctx->gp.h) : 0.f;
+  pa.listed = (cert && listed_pass) ? 1 : 0;
+  pa.cert_row0 = pl.grows;
+  {  // one segment per wavefront, the same for both kernels
+    const int64_t nseg = 4 * (int64_t)pl.grows;
+    pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
+    if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
+  }
+  pl.nparts = pa.listed ? 2 * pl.grows : pl.grows;
+  // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
+  pl.tail = pl.fused && ctx->use_tail;
+  pa.tail = pl.tail ? (fuse_solve ? 2 : 1) : 0;
+  pa.nparts = pl.nparts; pa.has_normals = ctx->has_tgt_normals; pa.log_rows = ctx->log_rows; pa.log = ctx->log;
+  pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
+  return pl;
+}
+
+int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
+  const bool prof = ctx->prof_on && ctx->prof_n < 340;
+  if (prof) {  // three events per pass: before the search kernel, after it, after the accumulation kernel (alternative path)
+    for (int k = 0; k < 3; k++)
+      if (!ctx->prof_ev[3 * ctx->prof_n + k]) O3D_HIP(ctx, hipEventCreate(&ctx->prof_ev[3 * ctx->prof_n + k]));
+    O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n], ctx->stream));
+  }
+  const PassPlan pl = plan_pass(ctx, dev_sums_out, fuse_solve, ctx->enq_passes > 1);  // enq_passes counts this pass already
+  const PassArgs &pa = pl.pa;
+  const int grows = pl.grows, nparts = pl.nparts;
   const int est = ctx->estimation;
 #define O3D_LAUNCH_EST(KERNEL, GRID, ...)                                                                                   \
   do {                                                                                                                     \
@@ -2075,34 +2140,8 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     else                                                                                                                   \
       hipLaunchKernelGGL(KERNEL<O3D_EST_POINT_TO_POINT>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);        \
   } while (0)
-  // Default: ONE kernel per pass -- the cooperative fp32-prefilter search with the exact fp64 resolution of what fp32
-  // cannot decide and the estimate's sums fused in.  Alternative (grids too large for the fp32 error bound, or forced by
-  // o3d_debug_set): the per-lane fp64 search followed by the accumulation kernel.  One partial row per workgroup.
-  const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
-  const int grows = fused ? ctx->search_grid : ctx->pass_grid;
-  int nparts = grows;
-  // Certificates: the bounds refer to the position of the previous pass -- not in hypothesis mode, where every pass starts
-  // from the untouched source, and not in the first pass, which has nothing to certify.  The work list is laid out for the
-  // search kernel's chunks, so k_icp_cert runs on the same grid.
-  const bool cert = fused && ctx->use_cert && !ctx->hyp_mode;
-  pa.gap = cert ? (float)(ctx->cert_gap * ctx->gp.h) : 0.f;
-  pa.listed = (cert && ctx->enq_passes > 1) ? 1 : 0;  // enq_passes counts this pass already
-  pa.cert_row0 = grows;
-  {  // one segment per wavefront, the same for both kernels
-    const int64_t nseg = 4 * (int64_t)grows;
-    pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
-    if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
-  }
-  if (pa.listed) {
-    O3D_LAUNCH_EST(k_icp_cert, grows, pa);
-    nparts = 2 * grows;
-  }
-  // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
-  const bool tail = fused && ctx->use_tail;
-  pa.tail = tail ? (fuse_solve ? 2 : 1) : 0;
-  pa.nparts = nparts; pa.has_normals = ctx->has_tgt_normals; pa.log_rows = ctx->log_rows; pa.log = ctx->log;
-  pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
-  if (fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
+  if (pa.listed) O3D_LAUNCH_EST(k_icp_cert, grows, pa);
+  if (pl.fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
     // (two instantiations rather than a run-time branch: with both gathers compiled in, the kernel spilled six registers)
     if (pa.tn && est == O3D_EST_POINT_TO_PLANE)
@@ -2124,7 +2163,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 2], ctx->stream));
     ctx->prof_n++;
   }
-  if (tail) {
+  if (pl.tail) {
   } else if (fuse_solve)
     hipLaunchKernelGGL(k_icp_finalize_solve, dim3(1), dim3(O3D_FIN_THREADS), 0, ctx->stream, ctx->partials, nparts, ctx->state,
                        dev_sums_out, ctx->has_tgt_normals, ctx->log, ctx->log_rows);
@@ -2133,6 +2172,100 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
                        dev_sums_out);
 #undef O3D_LAUNCH_EST
   O3D_HIP(ctx, hipGetLastError());
+  return O3D_OK;
+}
+
+// ---- the loop as HIP graphs --------------------------------------------------------------------------------------------
+// A registration of a small cloud is a chain of short kernels, and what its host thread pays is launches: 3.7 us of HIP
+// runtime per kernel, serialised across the threads of a batch (o3d_registration_icp_batch: 0.2 ms per pair of 200 k
+// points, half of what a pair costs).  The pass kernels also exist in a form that reads its arguments from device memory
+// (PassLaunch), so ONE pair of graphs per context -- O3D_GRAPH_PASSES passes each, the first beginning with the unlisted
+// first pass -- is instantiated once and replayed by every registration whose kernels and grid are the same; a
+// registration then costs one small upload of the arguments and a graph launch per O3D_GRAPH_PASSES iterations.  Passes
+// enqueued beyond the end of the loop return at once (IcpState::done), as they always did.
+// MEASURED (ROCm 7.2, MI355X): no gain -- hipGraphLaunch of eight kernel nodes costs the host as much as eight launches
+// (0.130 against 0.118 ms for 31 passes) and the batch of config 5 runs at 2230 pairs/s either way.  The path is kept
+// behind O3D_GRAPH=1, bit-identical to the plain launches (tests/test_gpu_tail.py), for runtimes where graphs are cheaper.
+namespace {
+template <int EST, bool TN>
+void *search_ind_fn() { return reinterpret_cast<void *>(&k_icp_search_coop_ind<EST, TN>); }
+template <int EST>
+void *cert_ind_fn() { return reinterpret_cast<void *>(&k_icp_cert_ind<EST>); }
+}  // namespace
+
+bool o3d_graph_eligible(o3d_ctx *ctx) {
+  if (!ctx->use_graph || ctx->prof_on || ctx->hyp_mode) return false;
+  const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
+  return fused && ctx->use_tail;
+}
+
+// Enqueues O3D_GRAPH_PASSES passes of the device-resident loop (pass + estimate each); first: the chunk begins with the
+// registration's first pass.
+int o3d_graph_passes(o3d_ctx *ctx, bool first) {
+  const PassPlan p0 = plan_pass(ctx, ctx->sums, 1, false), p1 = plan_pass(ctx, ctx->sums, 1, true);
+  if (!ctx->launch_uploaded) {
+    PassLaunch *h = reinterpret_cast<PassLaunch *>(ctx->pinned_launch);
+    static_assert(2 * sizeof(PassLaunch) <= 2048, "staging buffer of the pass arguments");
+    h[0].a = p0.pa; h[0].gp = ctx->gp;
+    h[1].a = p1.pa; h[1].gp = ctx->gp;
+    O3D_HIP(ctx, hipMemcpyAsync(ctx->d_launch, h, 2 * sizeof(PassLaunch), hipMemcpyHostToDevice, ctx->stream));
+    ctx->launch_uploaded = 1;
+  }
+  const int est = ctx->estimation;
+  const bool tn = p0.pa.tn != nullptr && est != O3D_EST_POINT_TO_POINT, cert = p1.pa.listed != 0;
+  const long long key = ((long long)p0.grows << 8) | (est << 4) | (tn ? 2 : 0) | (cert ? 1 : 0);
+  if (key != ctx->graph_key || !ctx->graph_exec[0]) {
+    for (int g = 0; g < 2; g++) {
+      if (ctx->graph_exec[g]) (void)hipGraphExecDestroy(ctx->graph_exec[g]);
+      ctx->graph_exec[g] = nullptr;
+    }
+    void *search_fn, *cert_fn;
+    if (est == O3D_EST_POINT_TO_PLANE) {
+      search_fn = tn ? search_ind_fn<O3D_EST_POINT_TO_PLANE, true>() : search_ind_fn<O3D_EST_POINT_TO_PLANE, false>();
+      cert_fn = cert_ind_fn<O3D_EST_POINT_TO_PLANE>();
+    } else if (est == O3D_EST_COLORED_ICP) {
+      search_fn = tn ? search_ind_fn<O3D_EST_COLORED_ICP, true>() : search_ind_fn<O3D_EST_COLORED_ICP, false>();
+      cert_fn = cert_ind_fn<O3D_EST_COLORED_ICP>();
+    } else {
+      search_fn = search_ind_fn<O3D_EST_POINT_TO_POINT, false>();
+      cert_fn = cert_ind_fn<O3D_EST_POINT_TO_POINT>();
+    }
+    const PassLaunch *d = reinterpret_cast<const PassLaunch *>(ctx->d_launch);
+    for (int g = 0; g < 2; g++) {
+      hipGraph_t graph;
+      O3D_HIP(ctx, hipGraphCreate(&graph, 0));
+      hipGraphNode_t prev = nullptr;
+      auto add = [&](void *fn, const PassLaunch *arg) -> hipError_t {
+        const PassLaunch *argv = arg;
+        void *params[] = {(void *)&argv};
+        hipKernelNodeParams kp{};
+        kp.func = fn;
+        kp.gridDim = dim3((unsigned)p0.grows);
+        kp.blockDim = dim3(O3D_BLOCK);
+        kp.sharedMemBytes = 0;
+        kp.kernelParams = params;
+        kp.extra = nullptr;
+        hipGraphNode_t node;
+        const hipError_t e = hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+        prev = node;
+        return e;
+      };
+      hipError_t e = hipSuccess;
+      for (int k = 0; k < O3D_GRAPH_PASSES && e == hipSuccess; k++) {
+        const bool unlisted = g == 0 && k == 0;
+        if (!unlisted && cert) e = add(cert_fn, d + 1);
+        if (e == hipSuccess) e = add(search_fn, unlisted ? d : d + 1);
+      }
+      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g], graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (e != hipSuccess) {
+        ctx->graph_key = -1;
+        O3D_HIP(ctx, e);
+      }
+    }
+    ctx->graph_key = key;
+  }
+  O3D_HIP(ctx, hipGraphLaunch(ctx->graph_exec[first ? 0 : 1], ctx->stream));
   return O3D_OK;
 }
 

@@ -14,6 +14,7 @@
 #define O3D_NUM_CU 256
 #define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
 #define O3D_NSUMS 32
+#define O3D_GRAPH_PASSES 8
 
 // ---- sums layout (per pass, fp64) -------------------------------------------
 // point-to-plane: [0..20] JTJ upper triangle row-major, [21..26] JTr, [27] sum r^2
@@ -93,6 +94,13 @@ struct o3d_ctx {
   uint32_t *brick_dir = nullptr;  // GridParams::dir of a bricked table
   size_t cap_dir = 0;
   int64_t n_bricks = 0;
+  // the loop as graphs (icp.hip, o3d_graph_passes)
+  int use_graph = 0;            // O3D_GRAPH=1 (plain launches by default: the graphs measured no gain)
+  void *d_launch = nullptr;     // two PassLaunch records in device memory: first pass, later passes
+  void *pinned_launch = nullptr;  // their staging buffer
+  int launch_uploaded = 0;      // ... holds the arguments of the current set-up
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // O3D_GRAPH_PASSES passes each: beginning with the first pass / later ones
+  long long graph_key = -1;     // kernels and grid the graphs were built for
   double knn_grid_h = -1.0;  // build_knn_grid: the cell size its last trial build was made for
 
   // source shard
