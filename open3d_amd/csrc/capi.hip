@@ -20,6 +20,8 @@
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
 bool o3d_graph_eligible(o3d_ctx *ctx);
+bool o3d_gang_eligible(o3d_ctx *ctx);
+int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool upload, bool first);
 int o3d_graph_passes(o3d_ctx *ctx, bool first);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
@@ -390,7 +392,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_launch};
+                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_launch,   ctx->d_gang};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -409,6 +411,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_launch) (void)hipHostFree(ctx->pinned_launch);
+  if (ctx->pinned_gang) (void)hipHostFree(ctx->pinned_gang);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -527,6 +530,14 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   ctx->pass_grid = (int)g;
   // k_icp_search_coop holds four workgroups per CU: one resident round of 4 x 256 workgroups, no tail
   int64_t gs = g < O3D_NUM_CU * 4 ? g : O3D_NUM_CU * 4;
+  if (ctx->gang_slots > 1) {
+    // one of several registrations advancing in lock step: the GANG fills the one resident round, every wavefront of a
+    // slot walks several trips (a launch of slots x 782 one-trip workgroups spends most of its time in their prologues
+    // and epilogues: measured 1850 pairs/s against 2300 one by one)
+    int64_t share = (O3D_NUM_CU * 4 / ctx->gang_slots) / 8 * 8;
+    if (share < 8) share = 8;
+    if (gs > share) gs = share;
+  }
   if (const char *e = getenv("O3D_SEARCH_GRID")) {  // tuning aid
     const long v = atol(e);
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
@@ -535,7 +546,9 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
   // Certificates cost a launch and a pass over the source of their own: they pay from a few hundred thousand points on
   // (steady-state iteration at 200 k points 26 us without, 31 us with; at 1 M 61 us without, 51 us with).
-  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : (n_src >= 400000 ? 1 : 0));  // tuning aids
+  // In a gang (o3d_registration_icp_batch) they always pay: their launch is shared by the whole gang and throughput counts,
+  // not the latency of one registration (4096 pairs of 200 k points: 2000 pairs/s without, 3100 with).
+  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : ((n_src >= 400000 || ctx->gang_slots > 1) ? 1 : 0));  // tuning aids
   ctx->use_tail = getenv("O3D_NO_TAIL") ? 0 : 1;  // tuning aid
   // measured: no gain on ROCm 7.2 (a graph launch of eight kernel nodes costs the host what eight launches cost, and the
   // batch of config 5 runs at the same 2230 pairs/s either way), so the plain launches stay the default
@@ -886,16 +899,27 @@ struct HostBarrier {
   const int n;
   std::atomic<int> waiting{0};
   std::atomic<unsigned> gen{0};
+  std::atomic<int> votes[2] = {{0}, {0}};  // by generation parity: the OR of what the arriving threads bring
+  int result[2] = {0, 0};
   explicit HostBarrier(int n_) : n(n_) {}
-  void wait() {
+  // Returns the OR of every thread's `vote` for THIS meeting.  A decision that all threads must take alike (stop, give up)
+  // has to travel this way: a flag set by a fast thread on its way to the next meeting could be seen by a slow thread still
+  // leaving this one, which would then leave the loop one meeting early and strand the others (seen as a rare hang of the
+  // multi-context tests in a long process).  A thread can be at most one meeting ahead, so two slots suffice.
+  int wait(int vote) {
     const unsigned g = gen.load(std::memory_order_acquire);
+    const int slot = (int)(g & 1u);
+    if (vote) votes[slot].fetch_or(vote, std::memory_order_acq_rel);
     if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      result[slot] = votes[slot].exchange(0, std::memory_order_acq_rel);
       waiting.store(0, std::memory_order_relaxed);
+      const int r = result[slot];
       gen.store(g + 1, std::memory_order_release);
-      return;
+      return r;
     }
     for (unsigned spins = 0; gen.load(std::memory_order_acquire) == g; spins++)
       if (spins > 2000) std::this_thread::yield();
+    return result[slot];
   }
 };
 }  // namespace
@@ -923,7 +947,6 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
     }
   }
   HostBarrier bar(G);
-  std::atomic<int> failed(0), stop(0);
   std::vector<int> status((size_t)G, O3D_OK);
   const bool can_break = rel_fitness > 0.0 && rel_rmse > 0.0;
   const int kChunk = 6;
@@ -934,10 +957,11 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
     const int64_t lo = n_src * r / G, hi = n_src * (r + 1) / G;
     int st = o3d_icp_setup(c, src_xyz ? src_xyz + 3 * lo : nullptr, hi - lo, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation,
                            with_scaling, rel_fitness, rel_rmse, max_iter, mem, n_src);
+    bool any_failed = false, want_stop = false;
     auto sync_point = [&]() {  // every rank arrives, whatever happened to it; afterwards all agree on whether to go on
-      if (st != O3D_OK) failed.store(1);
-      bar.wait();
-      return failed.load() == 0;
+      const int v = bar.wait((st != O3D_OK ? 1 : 0) | (want_stop ? 2 : 0));
+      if (v & 1) any_failed = true;
+      return v == 0;
     };
     double *box = m->mailbox_dev[(size_t)r];
     volatile int *flag = reinterpret_cast<volatile int *>((char *)c->pinned + 3072);
@@ -952,10 +976,10 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
         // rank 0 looks at the flag a chunk of iterations after it was copied (the device never waits for the host)
         if (r == 0 && st == O3D_OK && pending && it % kChunk == 0) {
           if (hipEventSynchronize(c->poll_ev) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipEventSynchronize");
-          else if (*flag) stop.store(1);
+          else if (*flag) want_stop = true;
           pending = false;
         }
-        if (!sync_point() || stop.load()) break;
+        if (!sync_point()) break;
         for (int q = 0; q < G && st == O3D_OK; q++)  // the sums of the ranks on other devices (same device: same stream)
           if (m->ranks[(size_t)q]->device != c->device && hipStreamWaitEvent(c->stream, m->xev[(size_t)(par * G + q)], 0) != hipSuccess)
             st = o3d_fail(c, O3D_ERR_HIP, "hipStreamWaitEvent");
@@ -969,7 +993,7 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
       }
     }
     // results: the transformation / fitness / rmse are the same on every rank; the correspondences are the rank's shard
-    if (st == O3D_OK && failed.load() == 0)
+    if (st == O3D_OK && !any_failed)
       st = o3d_icp_finish(c, mem, r == 0 ? out_T : nullptr, out_corr ? out_corr + lo : nullptr, r == 0 ? out_n_corr : nullptr,
                           r == 0 ? out_fitness : nullptr, r == 0 ? out_rmse : nullptr, r == 0 ? out_iters : nullptr);
     else if (c->stream)
@@ -1056,7 +1080,14 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   if (n_workers <= 0) n_workers = 4;
   if (n_workers > 16) n_workers = 16;
   if ((int64_t)n_workers > n_pairs) n_workers = (int)n_pairs;
-  while ((int)ctx->workers.size() < n_workers) {
+  // Each worker thread advances a gang of registrations in lock step (icp.hip, o3d_launch_pass_gang): one launch per pass
+  // kernel for the whole gang.  O3D_BATCH_GANG=1 gives the registrations one by one (the round-1 form).
+  int gang = 16;
+  if (const char *e = getenv("O3D_BATCH_GANG")) gang = atoi(e);
+  if (gang < 1) gang = 1;
+  if (gang > O3D_GANG_MAX) gang = O3D_GANG_MAX;
+  if ((int64_t)gang * n_workers > n_pairs) gang = (int)((n_pairs + n_workers - 1) / n_workers);
+  while ((int)ctx->workers.size() < n_workers * gang) {
     o3d_ctx *w = nullptr;
     const int st = o3d_ctx_create(ctx->device, &w);
     if (st != O3D_OK) return o3d_fail(ctx, st, "batch worker context: %s", o3d_last_error(nullptr));
@@ -1065,29 +1096,73 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   static const double kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::atomic<int64_t> next(0);
   std::vector<int> first_status((size_t)n_workers, O3D_OK);
+  std::vector<std::string> first_error((size_t)n_workers);
   auto work = [&](int wi) {
-    o3d_ctx *w = ctx->workers[(size_t)wi];
-    w->use_tile = ctx->use_tile;
-    for (;;) {
-      const int64_t p = next.fetch_add(1);
-      if (p >= n_pairs) break;
-      double T[16], fit = 0.0, rmse = 0.0;
-      int64_t nc = 0;
-      int iters = 0;
-      const int st = o3d_registration_icp(w, src_xyz[p], n_src[p], tgt_xyz[p], tgt_nrm ? tgt_nrm[p] : nullptr, n_tgt[p], max_dist,
-                                          init ? init + 16 * p : kIdentity, estimation, with_scaling, rel_fitness, rel_rmse,
-                                          max_iter, mem, T, (out_corr && out_corr[p]) ? out_corr[p] : nullptr, &nc, &fit, &rmse,
-                                          &iters);
+    o3d_ctx *const *slot = &ctx->workers[(size_t)wi * (size_t)gang];
+    o3d_ctx *lead = slot[0];
+    DeviceGuard guard(lead->device);
+    for (int k = 0; k < gang; k++) {
+      slot[k]->use_tile = ctx->use_tile;
+      slot[k]->gang_slots = gang;
+    }
+    auto fail = [&](int64_t p, int st, o3d_ctx *c) {
       if (out_status) out_status[p] = st;
-      if (st != O3D_OK) {
-        if (first_status[(size_t)wi] == O3D_OK) first_status[(size_t)wi] = st;
-        continue;  // the other pairs are independent
+      if (first_status[(size_t)wi] == O3D_OK) { first_status[(size_t)wi] = st; first_error[(size_t)wi] = o3d_last_error(c); }
+    };
+    for (;;) {
+      const int64_t base = next.fetch_add(gang);
+      if (base >= n_pairs) break;
+      const int m = (int)std::min<int64_t>(gang, n_pairs - base);
+      o3d_ctx *live[O3D_GANG_MAX];
+      int64_t live_pair[O3D_GANG_MAX];
+      int nl = 0;
+      // Set-ups: every slot on its own stream, so that their chains of small kernels (sorts, table, gathers -- half of a
+      // batch's kernel time when they ran one behind the other) overlap; the passes then run on the first slot's stream.
+      for (int k = 0; k < m; k++) {
+        const int64_t p = base + k;
+        slot[k]->stream = slot[k]->own_stream;
+        const int st = o3d_icp_setup(slot[k], src_xyz[p], n_src[p], tgt_xyz[p], tgt_nrm ? tgt_nrm[p] : nullptr, n_tgt[p], max_dist,
+                                     init ? init + 16 * p : kIdentity, estimation, with_scaling, rel_fitness, rel_rmse, max_iter, mem,
+                                     n_src[p]);
+        if (st != O3D_OK) { fail(p, st, slot[k]); continue; }  // the other pairs are independent
+        live[nl] = slot[k]; live_pair[nl] = p; nl++;
       }
-      if (out_T) memcpy(out_T + 16 * p, T, sizeof T);
-      if (out_n_corr) out_n_corr[p] = nc;
-      if (out_fitness) out_fitness[p] = fit;
-      if (out_rmse) out_rmse[p] = rmse;
-      if (out_iters) out_iters[p] = iters;
+      for (int k = 0; k < nl; k++) {
+        (void)hipStreamSynchronize(live[k]->own_stream);
+        live[k]->stream = lead->own_stream;
+      }
+      bool together = nl > 1;
+      for (int k = 0; k < nl && together; k++)
+        together = o3d_gang_eligible(live[k]) && live[k]->use_cert == live[0]->use_cert && live[k]->tn_valid == live[0]->tn_valid;
+      int loop_status = O3D_OK;
+      if (together) {
+        for (int pass = 0; pass <= max_iter && loop_status == O3D_OK; pass++) {
+          for (int k = 0; k < nl; k++) { live[k]->enq_passes++; live[k]->sums_valid = 1; }
+          loop_status = o3d_launch_pass_gang(lead, live, nl, pass == 0, pass == 0);
+        }
+      }
+      for (int k = 0; k < nl; k++) {
+        const int64_t p = live_pair[k];
+        int st = loop_status;
+        if (together && st != O3D_OK) { fail(p, st, lead); continue; }
+        if (!together) st = run_icp_loop(live[k], max_iter);
+        double T[16], fit = 0.0, rmse = 0.0;
+        int64_t nc = 0;
+        int iters = 0;
+        if (st == O3D_OK)
+          st = o3d_icp_finish(live[k], mem, T, (out_corr && out_corr[p]) ? out_corr[p] : nullptr, &nc, &fit, &rmse, &iters);
+        if (st != O3D_OK) { fail(p, st, live[k]); continue; }
+        if (out_status) out_status[p] = O3D_OK;
+        if (out_T) memcpy(out_T + 16 * p, T, sizeof T);
+        if (out_n_corr) out_n_corr[p] = nc;
+        if (out_fitness) out_fitness[p] = fit;
+        if (out_rmse) out_rmse[p] = rmse;
+        if (out_iters) out_iters[p] = iters;
+      }
+    }
+    for (int k = 0; k < gang; k++) {
+      slot[k]->stream = slot[k]->own_stream;
+      slot[k]->gang_slots = 0;
     }
   };
   std::vector<std::thread> threads;
@@ -1096,7 +1171,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   for (auto &t : threads) t.join();
   for (int wi = 0; wi < n_workers; wi++)
     if (first_status[(size_t)wi] != O3D_OK)
-      return o3d_fail(ctx, first_status[(size_t)wi], "batch: %s", o3d_last_error(ctx->workers[(size_t)wi]));
+      return o3d_fail(ctx, first_status[(size_t)wi], "batch: %s", first_error[(size_t)wi].c_str());
   return O3D_OK;
 }
 

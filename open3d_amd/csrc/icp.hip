@@ -298,6 +298,7 @@ struct PassArgs {
   double thr;
   // the pass's last kernel ends the pass itself (pass_tail): 0 = no, 1 = sum the partial rows, 2 = ... and run the estimate
   int tail;
+  int grid_x;            // workgroups of this pass (a batched launch over several registrations may bring more: they leave)
   int nparts;            // partial rows of the pass
   int has_normals;
   int log_rows;
@@ -335,7 +336,7 @@ __device__ __forceinline__ void store_device_coherent(double *p, double v) {
 
 // Defined behind the estimate's algebra below.  Every thread of the workgroup calls it once the workgroup's partial row
 // has been stored.
-__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk);
+__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk, unsigned gdim);
 
 __device__ __forceinline__ void load_update(const IcpState *st, double (&T)[12], double (&w)[4]) {
 #pragma unroll
@@ -770,9 +771,9 @@ struct WaveRange {
   unsigned chunk, seg;
   int64_t beg, end;
 };
-__device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len) {
+__device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, unsigned gdim) {
   WaveRange r;
-  r.chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  r.chunk = (blockIdx.x & 7u) * (gdim >> 3) + (blockIdx.x >> 3);
   r.seg = r.chunk * 4u + (threadIdx.x >> 6);
   r.beg = (int64_t)r.seg * seg_len;
   r.end = r.beg + seg_len;
@@ -787,7 +788,9 @@ __device__ __forceinline__ void cert_body(const PassArgs &a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
   static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
   const int tid = threadIdx.x, lane = tid & 63;
-  const WaveRange wr = wave_range(a.n_src, a.seg_len);
+  const unsigned gdim = (unsigned)a.grid_x;
+  if (blockIdx.x >= gdim) return;
+  const WaveRange wr = wave_range(a.n_src, a.seg_len, gdim);
   if (a.st->skip_cert) {  // the pending update moves the cloud farther than any bound reaches: everything is searched
     if (tid < O3D_NSUMS) a.partials[((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid] = 0.0;
     return;
@@ -886,6 +889,11 @@ template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_ind(const PassLaunch *__restrict__ pl) {
   cert_body<EST>(pl->a);
 }
+// ... and for several registrations in lock step (o3d_registration_icp_batch): blockIdx.y names the registration
+template <int EST>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch(const PassLaunch *__restrict__ pl) {
+  cert_body<EST>(pl[blockIdx.y].a);
+}
 
 // The cooperative search (see above CoopWave).  PassArgs::listed: the queries are the work list k_icp_cert left behind
 // (already moved by the pending update), unless IcpState::skip_cert says that k_icp_cert stood aside.
@@ -893,7 +901,8 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_ind(const PassLaunch 
 // any other query is at least a cell size away from every target point and has no correspondence.
 template <int EST, bool TN>
 __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridParams &gp) {
-  if (a.st->done) return;
+  const unsigned gdim = (unsigned)a.grid_x;
+  if (blockIdx.x >= gdim || a.st->done) return;
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
   static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -904,7 +913,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   const int apply = listed ? 0 : a.st->apply_update;
   double T[12], w[4];
   load_update(a.st, T, w);
-  const WaveRange wr = wave_range(a.n_src, a.seg_len);
+  const WaveRange wr = wave_range(a.n_src, a.seg_len, gdim);
   const int64_t nq = listed ? (int64_t)a.work_count[wr.seg] : wr.end - wr.beg;  // wave-uniform
   const float hf = (float)gp.h;
   const float err = kF32Err * hf * hf;
@@ -1127,7 +1136,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   if (nq > 0) consume();
   __syncthreads();
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
-  pass_tail(a, reinterpret_cast<double *>(wls), wr.chunk);
+  pass_tail(a, reinterpret_cast<double *>(wls), wr.chunk, gdim);
 }
 
 template <int EST, bool TN>
@@ -1137,6 +1146,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, Gr
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_ind(const PassLaunch *__restrict__ pl) {
   search_coop_body<EST, TN>(pl->a, pl->gp);
+}
+template <int EST, bool TN>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_batch(const PassLaunch *__restrict__ pl) {
+  search_coop_body<EST, TN>(pl[blockIdx.y].a, pl[blockIdx.y].gp);
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -1614,12 +1627,12 @@ __device__ __forceinline__ bool last_to_arrive(unsigned *ticket, unsigned expect
   return s_last != 0;
 }
 
-__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk) {
+__device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsigned chunk, unsigned gdim) {
   if (!a.tail) return;
   const int tid = threadIdx.x, k = tid & 31, uq = tid >> 5;
   const unsigned g = chunk & 31u;
-  const unsigned ngroups = gridDim.x < 32u ? gridDim.x : 32u;
-  if (!last_to_arrive(a.tickets + g, (gridDim.x - g + 31u) / 32u)) return;
+  const unsigned ngroups = gdim < 32u ? gdim : 32u;
+  if (!last_to_arrive(a.tickets + g, (gdim - g + 31u) / 32u)) return;
   double (*s8)[O3D_NSUMS] = reinterpret_cast<double (*)[O3D_NSUMS]>(lds);
   double acc = 0.0;
   for (int b0 = (int)g; b0 < a.nparts; b0 += 32 * 32) {  // workgroup-uniform
@@ -2111,6 +2124,7 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
     pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
     if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
   }
+  pa.grid_x = pl.grows;
   pl.nparts = pa.listed ? 2 * pl.grows : pl.grows;
   // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
   pl.tail = pl.fused && ctx->use_tail;
@@ -2266,6 +2280,61 @@ int o3d_graph_passes(o3d_ctx *ctx, bool first) {
     ctx->graph_key = key;
   }
   O3D_HIP(ctx, hipGraphLaunch(ctx->graph_exec[first ? 0 : 1], ctx->stream));
+  return O3D_OK;
+}
+
+// ---- several registrations in lock step ---------------------------------------------------------------------------------
+// A batch of small registrations (BASELINE config 5) one by one is a stream of 25 us kernels, each filling three quarters
+// of the GPU for one latency chain, with the gaps of dependent launches in between (profiles/r02_n_*).  Here `n` slots --
+// contexts that have been set up for one registration each, all on `lead`'s stream -- advance together: ONE launch per
+// pass kernel over a grid of (workgroups of the largest slot) x n, the slot's arguments read from device memory by
+// blockIdx.y.  Everything a slot computes is what it would compute alone (its own state, partial rows, counters).
+bool o3d_gang_eligible(o3d_ctx *ctx) {
+  if (ctx->prof_on || ctx->hyp_mode) return false;
+  const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
+  return fused && ctx->use_tail;
+}
+
+// upload: the slots have just been set up (first pass of the gang's loop).  first: the unlisted first pass.
+int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool upload, bool first) {
+  if (n < 1 || n > O3D_GANG_MAX) return o3d_fail(lead, O3D_ERR_INVALID_ARG, "gang of %d registrations", n);
+  if (!lead->d_gang) {
+    O3D_HIP(lead, hipMalloc(&lead->d_gang, 2 * O3D_GANG_MAX * sizeof(PassLaunch)));
+    O3D_HIP(lead, hipHostMalloc(&lead->pinned_gang, 2 * O3D_GANG_MAX * sizeof(PassLaunch), hipHostMallocDefault));
+  }
+  const int est = slots[0]->estimation;
+  if (upload) {
+    PassLaunch *h = reinterpret_cast<PassLaunch *>(lead->pinned_gang);
+    int gx = 0;
+    bool cert = false, tn = false;
+    for (int k = 0; k < n; k++) {
+      o3d_ctx *c = slots[k];
+      const PassPlan p0 = plan_pass(c, c->sums, 1, false), p1 = plan_pass(c, c->sums, 1, true);
+      h[k].a = p0.pa; h[k].gp = c->gp;
+      h[O3D_GANG_MAX + k].a = p1.pa; h[O3D_GANG_MAX + k].gp = c->gp;
+      const bool ck = p1.pa.listed != 0, tk = p0.pa.tn != nullptr && est != O3D_EST_POINT_TO_POINT;
+      if (k > 0 && (ck != cert || tk != tn || c->estimation != est))
+        return o3d_fail(lead, O3D_ERR_STATE, "gang: the slots do not run the same kernels");
+      cert = ck; tn = tk;
+      gx = p0.grows > gx ? p0.grows : gx;
+    }
+    O3D_HIP(lead, hipMemcpyAsync(lead->d_gang, h, 2 * O3D_GANG_MAX * sizeof(PassLaunch), hipMemcpyHostToDevice, lead->stream));
+    lead->gang_grid = gx; lead->gang_cert = cert ? 1 : 0; lead->gang_tn = tn ? 1 : 0;
+  }
+  const PassLaunch *d = reinterpret_cast<const PassLaunch *>(lead->d_gang) + (first ? 0 : O3D_GANG_MAX);
+  const dim3 grid((unsigned)lead->gang_grid, (unsigned)n), block(O3D_BLOCK);
+  hipStream_t st = lead->stream;
+  if (!first && lead->gang_cert) {
+    if (est == O3D_EST_POINT_TO_PLANE) hipLaunchKernelGGL(k_icp_cert_batch<O3D_EST_POINT_TO_PLANE>, grid, block, 0, st, d);
+    else if (est == O3D_EST_COLORED_ICP) hipLaunchKernelGGL(k_icp_cert_batch<O3D_EST_COLORED_ICP>, grid, block, 0, st, d);
+    else hipLaunchKernelGGL(k_icp_cert_batch<O3D_EST_POINT_TO_POINT>, grid, block, 0, st, d);
+  }
+  if (est == O3D_EST_POINT_TO_PLANE && lead->gang_tn) hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_POINT_TO_PLANE, true>), grid, block, 0, st, d);
+  else if (est == O3D_EST_POINT_TO_PLANE) hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_POINT_TO_PLANE, false>), grid, block, 0, st, d);
+  else if (est == O3D_EST_COLORED_ICP && lead->gang_tn) hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_COLORED_ICP, true>), grid, block, 0, st, d);
+  else if (est == O3D_EST_COLORED_ICP) hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_COLORED_ICP, false>), grid, block, 0, st, d);
+  else hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_POINT_TO_POINT, false>), grid, block, 0, st, d);
+  O3D_HIP(lead, hipGetLastError());
   return O3D_OK;
 }
 

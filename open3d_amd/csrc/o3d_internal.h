@@ -15,6 +15,7 @@
 #define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
 #define O3D_NSUMS 32
 #define O3D_GRAPH_PASSES 8
+#define O3D_GANG_MAX 32  // registrations advancing in lock step (o3d_launch_pass_gang)
 
 // ---- sums layout (per pass, fp64) -------------------------------------------
 // point-to-plane: [0..20] JTJ upper triangle row-major, [21..26] JTr, [27] sum r^2
@@ -101,6 +102,10 @@ struct o3d_ctx {
   int launch_uploaded = 0;      // ... holds the arguments of the current set-up
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // O3D_GRAPH_PASSES passes each: beginning with the first pass / later ones
   long long graph_key = -1;     // kernels and grid the graphs were built for
+  // several registrations in lock step (icp.hip, o3d_launch_pass_gang): the lead context's argument table
+  void *d_gang = nullptr, *pinned_gang = nullptr;
+  int gang_grid = 0, gang_cert = 0, gang_tn = 0;
+  int gang_slots = 0;  // > 1: this context is one slot of a gang of that many (set-up sizes its share of the grid)
   double knn_grid_h = -1.0;  // build_knn_grid: the cell size its last trial build was made for
 
   // source shard

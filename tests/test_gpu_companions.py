@@ -330,8 +330,8 @@ def test_device_scene_generator_matches_numpy(ctx):
 
 def test_batch_of_200k_pairs_matches_single_calls(ctx, oracle):
     """BASELINE config 5 shape (200 k x 200 k, point-to-plane, 30 fixed iterations), clouds generated on the device: a
-    handful of pairs through o3d_registration_icp_batch with 4 workers must equal their single calls bit for bit, and one
-    of them the oracle."""
+    handful of pairs through o3d_registration_icp_batch with 4 workers must equal their single calls (correspondences bit
+    for bit, the transformation to 1e-12), and one of them the oracle."""
     import ctypes as C
     import torch
     from open3d_amd import _lib, synthetic
@@ -359,7 +359,10 @@ def test_batch_of_200k_pairs_matches_single_calls(ctx, oracle):
         ctx.check(ctx._lib.o3d_registration_icp(ctx.handle, _lib.ptr(p["source"]), n, _lib.ptr(p["target"]), _lib.ptr(p["normals"]), n, 2 * s,
                                                 _lib.colmajor(np.eye(4)).ctypes.data_as(_lib.c_dp), 2, 0, 0.0, 0.0, 30, _lib.MEM_DEVICE,
                                                 T1.ctypes.data_as(_lib.c_dp), _lib.ptr(c1), C.byref(nc1), C.byref(f1), C.byref(r1), C.byref(it1)))
-        assert np.array_equal(T[k], T1) and nc[k] == nc1.value and fit[k] == f1.value and rmse[k] == r1.value
+        # the pairs of a batch advance in lock step on a shared grid (o3d_launch_pass_gang): fewer, longer workgroups per pair
+        # than the single call uses, so the fp64 sums are added in another order -- same correspondences, same count, the
+        # transformation equal to rounding
+        assert np.abs(T[k] - T1).max() < 1e-12 and nc[k] == nc1.value and fit[k] == f1.value and abs(rmse[k] - r1.value) < 1e-14
         assert torch.equal(corr[k], c1)
         assert np.abs(_lib.from_colmajor(T[k]) - p["T_true"]).max() < 1e-3
     p = pairs[2]
