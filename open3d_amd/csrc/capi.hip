@@ -554,7 +554,6 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   // batch of config 5 runs at the same 2230 pairs/s either way), so the plain launches stay the default
   ctx->use_graph = getenv("O3D_GRAPH") ? 1 : 0;
   ctx->launch_uploaded = 0;
-  O3D_HIP(ctx, hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * 64, ctx->stream));  // (they return to zero by themselves)
   if (const char *e = getenv("O3D_CERT_GAP")) {
     const double v = atof(e);
     if (v >= 0.0 && v <= 1.0) ctx->cert_gap = v;

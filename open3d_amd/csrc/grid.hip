@@ -224,7 +224,9 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__restrict__ xyz, const double *__restrict__ nrm,
                                                               const uint32_t *__restrict__ vals, int64_t n_grid, GridParams gp,
                                                               double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted,
-                                                              float4 *__restrict__ tgt_local, double4 *__restrict__ tn_sorted) {
+                                                              float4 *__restrict__ tgt_local, double4 *__restrict__ tn_sorted,
+                                                              int64_t n_pad) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) tgt_local[n_pad + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the read-ahead padding
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const uint32_t i = vals[p];
     double4 q;
@@ -398,9 +400,13 @@ __device__ __forceinline__ uint64_t hilbert3(uint32_t x0, uint32_t x1, uint32_t 
 // Source ordering key: Hilbert index of the target-grid cell of the (init-transformed) source point, clamped into the
 // grid.  Only the processing ORDER depends on it -- consecutive points form compact patches of cells, which is what
 // the tile pass stages into LDS; results are scattered back by original index.
+struct InitT {  // the initial transformation, column-major, as a kernel argument (no upload of its own)
+  double m[16];
+};
 __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            const double *__restrict__ T, int apply, int bits, int drop,
+                                                            InitT Tm, int apply, int bits, int drop,
                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const double *T = Tm.m;
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     if (apply) {
@@ -418,9 +424,12 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restr
 }
 
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_source(const double *__restrict__ xyz, const uint32_t *__restrict__ vals,
-                                                              int64_t n, double *__restrict__ src_sorted) {
+                                                              int64_t n, double *__restrict__ src_sorted,
+                                                              uint32_t *__restrict__ pos_sorted, float *__restrict__ lb_sorted) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const size_t i = vals[p];
+    pos_sorted[p] = 0xFFFFFFFFu;  // no previous match ...
+    lb_sorted[p] = 0.f;           // ... and no bound (two memsets less per set-up)
     src_sorted[3 * p] = xyz[3 * i];
     src_sorted[3 * p + 1] = xyz[3 * i + 1];
     src_sorted[3 * p + 2] = xyz[3 * i + 2];
@@ -527,7 +536,6 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
     // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
-    O3D_HIP(ctx, hipMemsetAsync(ctx->tgt_local + n, 0, sizeof(float4) * 4, ctx->stream));
     if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
     want_tn = dev_nrm && allow_bricks && !getenv("O3D_NO_TN");  // (the ICP set-up; the switch is a tuning aid)
     if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double4) * 2 * (size_t)n));
@@ -549,9 +557,14 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
     O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
-    hipLaunchKernelGGL(k_target_keys64, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint64_t *)keys, (uint32_t *)vals);
-    O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, (uint32_t *)vals, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
-                               ceil_log2((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz + 1)));
+    {
+      const int bits = ceil_log2((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz + 1);
+      const bool odd = o3d_radix_sort_odd(bits);
+      uint64_t *k0 = (uint64_t *)(odd ? tkeys : keys), *k1 = (uint64_t *)(odd ? keys : tkeys);
+      uint32_t *v0 = (uint32_t *)(odd ? tvals : vals), *v1 = (uint32_t *)(odd ? vals : tvals);
+      hipLaunchKernelGGL(k_target_keys64, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, k0, v0);
+      O3D_TRY(o3d_radix_sort_u64(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
+    }
     hipLaunchKernelGGL(k_brick_mark, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys, nfinite, gp,
                        ctx->brick_dir);
     // rank of every brick that exists (a copy of the flags, scanned), and their number
@@ -603,10 +616,14 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
     O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
-    hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, (uint32_t *)keys,
-                       (uint32_t *)vals);
-    O3D_TRY(o3d_radix_sort_u32(ctx, (uint32_t *)keys, (uint32_t *)vals, (uint32_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist,
-                               n, ceil_log2((uint64_t)gp.ncell + 1)));
+    {  // the keys start in whichever pair of buffers makes the sorted result end in (keys, vals): no copy home
+      const int bits = ceil_log2((uint64_t)gp.ncell + 1);
+      const bool odd = o3d_radix_sort_odd(bits);
+      uint32_t *k0 = (uint32_t *)(odd ? tkeys : keys), *v0 = (uint32_t *)(odd ? tvals : vals);
+      uint32_t *k1 = (uint32_t *)(odd ? keys : tkeys), *v1 = (uint32_t *)(odd ? vals : tvals);
+      hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, k0, v0);
+      O3D_TRY(o3d_radix_sort_u32(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
+    }
     if (ntab > (4u << 20))
       hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
                          (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
@@ -618,7 +635,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
                        (const uint32_t *)vals, nfinite, gp, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr,
-                       ctx->tgt_local, want_tn ? ctx->tn_sorted : nullptr);
+                       ctx->tgt_local, want_tn ? ctx->tn_sorted : nullptr, n);
   ctx->tn_valid = (want_tn && nfinite > 0) ? 1 : 0;
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
@@ -651,19 +668,15 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;
-  O3D_HIP(ctx, hipMemsetAsync(ctx->pos_sorted, 0xFF, sizeof(uint32_t) * (size_t)n, ctx->stream));  // no previous match
-  O3D_HIP(ctx, hipMemsetAsync(ctx->lb_sorted, 0, sizeof(float) * (size_t)n, ctx->stream));          // ... and no bound
   const size_t ntiles = o3d_sort_num_tiles(n);
   const size_t nh = 256 * ntiles;
-  void *keys, *tkeys, *tvals, *hist, *dT;
+  void *keys, *tkeys, *tvals, *hist;
   O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint64_t) * (size_t)n, &keys));
   O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
   O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
   O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
-  O3D_TRY(o3d_scratch(ctx, 7, sizeof(double) * 16, &dT));
-  double *hT = (double *)ctx->pinned + 64;
-  for (int i = 0; i < 16; i++) hT[i] = init_colmajor[i];
-  O3D_HIP(ctx, hipMemcpyAsync(dT, hT, sizeof(double) * 16, hipMemcpyHostToDevice, ctx->stream));
+  InitT Tm;
+  for (int i = 0; i < 16; i++) Tm.m[i] = init_colmajor[i];
   const int g = grid_for(n);
   int axis_bits = ceil_log2((uint64_t)std::max(std::max(ctx->gp.nx, ctx->gp.ny), ctx->gp.nz));
   axis_bits = std::min(std::max(axis_bits, 1), 21);
@@ -671,14 +684,17 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   // neighbouring cells of the curve share a key and keep their given order; only the processing ORDER depends on the key).
   const int over = (3 * axis_bits) % 8;
   const int drop = (3 * axis_bits > 8 && over >= 1 && over <= 2) ? over : 0;
-  hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, (const double *)dT,
-                     apply_init, axis_bits, drop, (uint64_t *)keys, ctx->src_perm);
-  O3D_TRY(o3d_radix_sort_u64(ctx, (uint64_t *)keys, ctx->src_perm, (uint64_t *)tkeys, (uint32_t *)tvals, (uint32_t *)hist, n,
-                             3 * axis_bits - drop));
+  {  // the permutation must END in src_perm: with an odd number of radix passes it starts in the other buffer (no copy home)
+    const int bits = 3 * axis_bits - drop;
+    const bool odd = o3d_radix_sort_odd(bits);
+    uint64_t *k0 = (uint64_t *)(odd ? tkeys : keys), *k1 = (uint64_t *)(odd ? keys : tkeys);
+    uint32_t *v0 = odd ? (uint32_t *)tvals : ctx->src_perm, *v1 = odd ? ctx->src_perm : (uint32_t *)tvals;
+    hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, Tm, apply_init, axis_bits, drop,
+                       k0, v0);
+    O3D_TRY(o3d_radix_sort_u64(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
+  }
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
-                     ctx->src_sorted);
+                     ctx->src_sorted, ctx->pos_sorted, ctx->lb_sorted);
   O3D_HIP(ctx, hipGetLastError());
-  // (the pinned staging for T is rewritten by the next set-up on this context at the earliest; every path to it has
-  // synchronised the stream by then)
   return O3D_OK;
 }

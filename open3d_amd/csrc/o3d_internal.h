@@ -207,9 +207,10 @@ void o3d_xfer_destroy(o3d_ctx *ctx);
 // KeyT = uint32_t or uint64_t.  hist needs 256 * ntiles(n) uint32.
 size_t o3d_sort_num_tiles(int64_t n);
 int o3d_radix_sort_u32(o3d_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *tmp_keys, uint32_t *tmp_vals,
-                       uint32_t *hist, int64_t n, int bits);
+                       uint32_t *hist, int64_t n, int bits, bool copy_home = true);
 int o3d_radix_sort_u64(o3d_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *tmp_keys, uint32_t *tmp_vals,
-                       uint32_t *hist, int64_t n, int bits);
+                       uint32_t *hist, int64_t n, int bits, bool copy_home = true);
+bool o3d_radix_sort_odd(int bits);  // the sort of `bits` key bits ends in the tmp pair (see sort_scan.hip)
 // In-place exclusive prefix sum over n uint32 (n up to 2^31); block_sums needs ceil(n / 8192) + 1 uint32.
 size_t o3d_scan_num_blocks(int64_t n);
 int o3d_exclusive_scan_u32(o3d_ctx *ctx, uint32_t *data, uint32_t *block_sums, int64_t n);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_scan_apply(uint32_t *__restrict__
 
 template <typename KeyT>
 int radix_sort_impl(o3d_ctx *ctx, KeyT *keys, uint32_t *vals, KeyT *tmp_keys, uint32_t *tmp_vals, uint32_t *hist, int64_t n,
-                    int bits) {
+                    int bits, bool copy_home) {
   if (n <= 0) return O3D_OK;
   if (n >= (int64_t)1 << 31) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "radix sort: n=%lld exceeds 2^31-1", (long long)n);
   const uint32_t ntiles = (uint32_t)o3d_sort_num_tiles(n);
@@ -258,7 +258,7 @@ int radix_sort_impl(o3d_ctx *ctx, KeyT *keys, uint32_t *vals, KeyT *tmp_keys, ui
     KeyT *tk = ka; ka = kb; kb = tk;
     uint32_t *tv = va; va = vb; vb = tv;
   }
-  if (ka != keys) {  // odd number of passes: bring the result home
+  if (ka != keys && copy_home) {  // odd number of passes: bring the result home (or the caller started in the other pair)
     O3D_HIP(ctx, hipMemcpyAsync(keys, ka, sizeof(KeyT) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     O3D_HIP(ctx, hipMemcpyAsync(vals, va, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
   }
@@ -282,10 +282,17 @@ int o3d_exclusive_scan_u32(o3d_ctx *ctx, uint32_t *data, uint32_t *block_sums, i
 }
 
 int o3d_radix_sort_u32(o3d_ctx *ctx, uint32_t *keys, uint32_t *vals, uint32_t *tmp_keys, uint32_t *tmp_vals, uint32_t *hist,
-                       int64_t n, int bits) {
-  return radix_sort_impl<uint32_t>(ctx, keys, vals, tmp_keys, tmp_vals, hist, n, bits);
+                       int64_t n, int bits, bool copy_home) {
+  return radix_sort_impl<uint32_t>(ctx, keys, vals, tmp_keys, tmp_vals, hist, n, bits, copy_home);
 }
 int o3d_radix_sort_u64(o3d_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *tmp_keys, uint32_t *tmp_vals, uint32_t *hist,
-                       int64_t n, int bits) {
-  return radix_sort_impl<uint64_t>(ctx, keys, vals, tmp_keys, tmp_vals, hist, n, bits);
+                       int64_t n, int bits, bool copy_home) {
+  return radix_sort_impl<uint64_t>(ctx, keys, vals, tmp_keys, tmp_vals, hist, n, bits, copy_home);
+}
+// With an odd number of passes the result lands in the OTHER pair of buffers: a caller that can put its input there to
+// begin with (o3d_radix_sort_odd) and passes copy_home = false saves the two copies that bring it home.
+bool o3d_radix_sort_odd(int bits) {
+  int passes = (bits + 7) / 8;
+  if (passes < 1) passes = 1;
+  return (passes & 1) != 0;
 }
