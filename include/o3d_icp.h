@@ -141,8 +141,13 @@ O3D_API int o3d_registration_colored_icp(o3d_ctx *ctx, const double *src_xyz, co
  * (n_tgt[p] points; tgt_nrm may be NULL for point-to-point), init_colmajor + 16 p (init_colmajor NULL: identity) and
  * writes out_transformation + 16 p, out_fitness[p], out_inlier_rmse[p], out_iterations[p], out_n_corr[p] and, when
  * out_corr and out_corr[p] are non-NULL, n_src[p] correspondences.  The pairs are spread over `n_workers` host threads
- * (0: default 4), each with its own context and stream on ctx's device, so that the set-up of one pair overlaps the
- * loop of another.  out_status[p] (may be NULL) receives the pair's status; the return value is the first non-zero one. */
+ * (0: default 4) on ctx's device; each thread advances a GANG of registrations in lock step -- as many as put about six
+ * million source points into a launch, 32 at most, one for pairs that fill the GPU by themselves -- with one launch per
+ * pass kernel for the whole gang, so that small pairs do not pay a launch each, and the set-up of one gang overlaps the
+ * loop of another.  The context keeps one worker context (stream, grid and source buffers of a pair) per thread and gang
+ * slot until it is destroyed.  A pair's correspondences are those of its single call; its transformation agrees to
+ * rounding (the gang shares the GPU's resident round, so a pair's sums are added over fewer, longer workgroups).
+ * out_status[p] (may be NULL) receives the pair's status; the return value is the first non-zero one. */
 O3D_API int o3d_registration_icp_batch(o3d_ctx *ctx, int64_t n_pairs, const double *const *src_xyz, const int64_t *n_src,
                                const double *const *tgt_xyz, const double *const *tgt_nrm, const int64_t *n_tgt,
                                double max_correspondence_distance, const double *init_colmajor, int estimation,

@@ -1081,7 +1081,11 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   if ((int64_t)n_workers > n_pairs) n_workers = (int)n_pairs;
   // Each worker thread advances a gang of registrations in lock step (icp.hip, o3d_launch_pass_gang): one launch per pass
   // kernel for the whole gang.  O3D_BATCH_GANG=1 gives the registrations one by one (the round-1 form).
-  int gang = 16;
+  // As many registrations per gang as put about six million source points into a launch (a pair of 200 k points: 30;
+  // a pair that fills the GPU by itself: 1 -- and every slot holds its pair's buffers, so large pairs must not multiply).
+  int64_t largest = 1;
+  for (int64_t p = 0; p < n_pairs; p++) largest = std::max<int64_t>(largest, std::max<int64_t>(n_src[p], n_tgt[p]));
+  int gang = (int)std::min<int64_t>(O3D_GANG_MAX, std::max<int64_t>(1, 6000000 / largest));
   if (const char *e = getenv("O3D_BATCH_GANG")) gang = atoi(e);
   if (gang < 1) gang = 1;
   if (gang > O3D_GANG_MAX) gang = O3D_GANG_MAX;

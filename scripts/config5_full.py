@@ -2,7 +2,7 @@
 """BASELINE config 5 in full on one GPU: 4096 independent pairs of 200 k x 200 k points, point-to-plane,
 ICPConvergenceCriteria(0, 0, 30), clouds and analytic target normals generated on the device (o3d_synthetic_pair: 59 GB that
 never cross PCIe), registered by o3d_registration_icp_batch.  Every pair's transformation is checked against the motion its
-scene was made with; a sample is registered again one by one and must give the same bits.
+scene was made with; a sample is registered again one by one and must give the same result to rounding (1e-12).
 usage: config5_full.py [pairs] [workers ...]"""
 import ctypes as C
 import json
@@ -64,6 +64,7 @@ for k in sample:
     ctx.check(ctx._lib.o3d_registration_icp(ctx.handle, src[k].data_ptr(), n, tgt[k].data_ptr(), nrm[k].data_ptr(), n, 2 * s,
                                             _lib.colmajor(np.eye(4)).ctypes.data_as(_lib.c_dp), 2, 0, 0.0, 0.0, 30, _lib.MEM_DEVICE,
                                             T1.ctypes.data_as(_lib.c_dp), None, C.byref(nc1), C.byref(f1), C.byref(r1), C.byref(it1)))
-    same += int(np.array_equal(T1, T[k]) and nc1.value == nc[k] and r1.value == rmse[k])
-out["sample_single_calls_identical"] = "%d of %d" % (same, len(sample))
+    # (a pair of a gang adds its sums over fewer, longer workgroups than its single call: equal to rounding)
+    same += int(np.abs(T1 - T[k]).max() < 1e-12 and nc1.value == nc[k] and abs(r1.value - rmse[k]) < 1e-14)
+out["sample_single_calls_equal_to_rounding"] = "%d of %d" % (same, len(sample))
 print(json.dumps(out))
