@@ -370,3 +370,43 @@ def test_batch_of_200k_pairs_matches_single_calls(ctx, oracle):
                                   rel_fitness=0.0, rel_rmse=0.0, max_iter=30)
     assert np.array_equal(corr[2].cpu().numpy(), ref.corr)
     assert np.abs(_lib.from_colmajor(T[2]) - ref.transformation).max() < 1e-6
+
+
+@pytest.mark.parametrize("est_name", ["p2plane", "p2p"])
+def test_batch_gangs_of_unequal_pairs_equal_one_by_one(ctx, oracle, est_name):
+    """The lock-step form of the batch (o3d_launch_pass_gang) with pairs of very different sizes in one gang -- every slot
+    brings its own number of workgroups to a launch sized for the largest, the others' surplus workgroups leave at once --
+    an empty source among them, pairs that converge at different iterations (default criteria) and more pairs than one gang
+    holds: against the same batch one registration at a time (O3D_BATCH_GANG=1), correspondences bit for bit, the
+    transformation to rounding; and two of them against the oracle."""
+    import os
+    geometry, reg = _reg()
+    sizes = [(60_000, 50_000), (150, 900), (9_000, 9_000), (0, 2_000), (33_000, 20_000), (700, 700), (20_000, 45_000), (2_500, 2_000),
+             (12_000, 12_500), (64, 4_000), (5_000, 5_100)]
+    sources, targets = [], []
+    for k, (ns, nt) in enumerate(sizes):
+        sc = make_scene(max(ns, 1), nt, cfg_id=700 + k, L=3.0, theta_deg=0.2 + 0.1 * (k % 4))
+        nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 0.2)
+        sources.append(geometry.PointCloud(sc["source"][:ns]))
+        targets.append(geometry.PointCloud(sc["target"], normals=nrm))
+    r = 0.1
+    est = reg.TransformationEstimationPointToPlane() if est_name == "p2plane" else reg.TransformationEstimationPointToPoint()
+    for crit in (reg.ICPConvergenceCriteria(), reg.ICPConvergenceCriteria(0.0, 0.0, 9)):
+        os.environ["O3D_BATCH_GANG"] = "4"        # 11 pairs over 2 threads: gangs of 4, 4 and 3
+        try:
+            got = reg.RegistrationICPBatch(sources, targets, r, None, est, crit, n_workers=2, want_corr=True, ctx=ctx)
+            os.environ["O3D_BATCH_GANG"] = "1"
+            want = reg.RegistrationICPBatch(sources, targets, r, None, est, crit, n_workers=2, want_corr=True, ctx=ctx)
+        finally:
+            os.environ.pop("O3D_BATCH_GANG", None)
+        for k in range(len(sizes)):
+            assert got[k].iterations_ == want[k].iterations_
+            assert np.array_equal(got[k].corr_, want[k].corr_)
+            assert np.abs(got[k].transformation_ - want[k].transformation_).max() < 1e-11
+            assert got[k].fitness_ == want[k].fitness_ and abs(got[k].inlier_rmse_ - want[k].inlier_rmse_) < 1e-13
+        for k in (0, 6):
+            ref = oracle.registration_icp(sources[k].points_, targets[k].points_, r, None, 2 if est_name == "p2plane" else 1,
+                                          targets[k].normals_, rel_fitness=crit.relative_fitness_, rel_rmse=crit.relative_rmse_,
+                                          max_iter=crit.max_iteration_)
+            assert got[k].iterations_ == ref.iterations and np.array_equal(got[k].corr_, ref.corr)
+            assert rel_err(got[k].transformation_, ref.transformation) < TOL
