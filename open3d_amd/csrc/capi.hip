@@ -412,6 +412,13 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_launch) (void)hipHostFree(ctx->pinned_launch);
   if (ctx->pinned_gang) (void)hipHostFree(ctx->pinned_gang);
+  if (ctx->gang_sort_own) {
+    for (uint32_t *b : {ctx->gang_sort_own->keys, ctx->gang_sort_own->vals, ctx->gang_sort_own->tkeys, ctx->gang_sort_own->tvals,
+                        ctx->gang_sort_own->hist})
+      if (b) (void)hipFree(b);
+    delete ctx->gang_sort_own;
+    ctx->gang_sort_own = nullptr;
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -1086,6 +1093,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   int64_t largest = 1;
   for (int64_t p = 0; p < n_pairs; p++) largest = std::max<int64_t>(largest, std::max<int64_t>(n_src[p], n_tgt[p]));
   int gang = (int)std::min<int64_t>(O3D_GANG_MAX, std::max<int64_t>(1, 6000000 / largest));
+  const bool use_gang_sort = !getenv("O3D_NO_GANG_SORT") && estimation != O3D_EST_COLORED_ICP;  // tuning aid
   if (const char *e = getenv("O3D_BATCH_GANG")) gang = atoi(e);
   if (gang < 1) gang = 1;
   if (gang > O3D_GANG_MAX) gang = O3D_GANG_MAX;
@@ -1119,20 +1127,67 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
       o3d_ctx *live[O3D_GANG_MAX];
       int64_t live_pair[O3D_GANG_MAX];
       int nl = 0;
+      // the gang's common sorter (o3d_gang_sort): room for every key of these pairs
+      o3d_gang_sort *gs = nullptr;
+      if (m > 1 && use_gang_sort) {
+        if (!lead->gang_sort_own) lead->gang_sort_own = new o3d_gang_sort();
+        gs = lead->gang_sort_own;
+        int64_t need = 0;
+        for (int k = 0; k < m; k++) need += std::max<int64_t>(n_src[base + k], 0) + std::max<int64_t>(n_tgt[base + k], 0);
+        const size_t nh = 256 * o3d_sort_num_tiles(need > 0 ? need : 1);
+        const size_t hneed = nh + o3d_scan_num_blocks((int64_t)nh) + 8;
+        bool ok = need < ((int64_t)1 << 31);
+        if (ok && ((size_t)need > gs->cap || hneed > gs->hist_cap)) {
+          (void)hipStreamSynchronize(lead->own_stream);
+          for (uint32_t **b : {&gs->keys, &gs->vals, &gs->tkeys, &gs->tvals, &gs->hist}) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+          }
+          gs->cap = gs->hist_cap = 0;
+          const size_t cap = (size_t)need + (size_t)need / 4 + 1024, hcap = hneed + hneed / 4;
+          ok = hipMalloc((void **)&gs->keys, 4 * cap) == hipSuccess && hipMalloc((void **)&gs->vals, 4 * cap) == hipSuccess &&
+               hipMalloc((void **)&gs->tkeys, 4 * cap) == hipSuccess && hipMalloc((void **)&gs->tvals, 4 * cap) == hipSuccess &&
+               hipMalloc((void **)&gs->hist, 4 * hcap) == hipSuccess;
+          if (ok) { gs->cap = cap; gs->hist_cap = hcap; }
+        }
+        if (!ok) gs = nullptr;  // (the slots then sort for themselves)
+        if (gs) { gs->used = 0; gs->jobs.clear(); }
+      }
       // Set-ups: every slot on its own stream, so that their chains of small kernels (sorts, table, gathers -- half of a
       // batch's kernel time when they ran one behind the other) overlap; the passes then run on the first slot's stream.
       for (int k = 0; k < m; k++) {
         const int64_t p = base + k;
         slot[k]->stream = slot[k]->own_stream;
+        slot[k]->gang_sort = gs;
         const int st = o3d_icp_setup(slot[k], src_xyz[p], n_src[p], tgt_xyz[p], tgt_nrm ? tgt_nrm[p] : nullptr, n_tgt[p], max_dist,
                                      init ? init + 16 * p : kIdentity, estimation, with_scaling, rel_fitness, rel_rmse, max_iter, mem,
                                      n_src[p]);
         if (st != O3D_OK) { fail(p, st, slot[k]); continue; }  // the other pairs are independent
         live[nl] = slot[k]; live_pair[nl] = p; nl++;
       }
-      for (int k = 0; k < nl; k++) {
-        (void)hipStreamSynchronize(live[k]->own_stream);
-        live[k]->stream = lead->own_stream;
+      for (int k = 0; k < m; k++) slot[k]->gang_sort = nullptr;
+      // (every slot, the failed ones too: their keys lie in the common buffer and must be at rest when the sort counts them)
+      for (int k = 0; k < m; k++) (void)hipStreamSynchronize(slot[k]->own_stream);
+      for (int k = 0; k < nl; k++) live[k]->stream = lead->own_stream;
+      if (gs && !gs->jobs.empty()) {
+        // every key of the gang in one sort (32 bits: job number on top), then what each slot queued behind its sort
+        int st = O3D_OK;
+        lead->stream = lead->own_stream;
+        if (gs->used > 0)
+          st = o3d_radix_sort_u32(lead, gs->keys, gs->vals, gs->tkeys, gs->tvals, gs->hist, gs->used, 32, false);  // 4 passes: ends at home
+        for (auto &job : gs->jobs) {
+          bool alive = false;
+          for (int k = 0; k < nl; k++) alive = alive || live[k] == job.owner;
+          if (!alive || st != O3D_OK) continue;
+          const int js = job.then(gs->keys + job.off, gs->vals + job.off);
+          if (js != O3D_OK) st = js;
+        }
+        gs->jobs.clear();
+        if (st != O3D_OK) {  // nothing of this gang can be trusted
+          (void)hipStreamSynchronize(lead->own_stream);
+          for (int k = 0; k < nl; k++) fail(live_pair[k], st, lead);
+          nl = 0;
+        }
       }
       bool together = nl > 1;
       for (int k = 0; k < nl && together; k++)

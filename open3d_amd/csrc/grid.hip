@@ -118,7 +118,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_bounds_final(const Bounds6 *__res
 // Non-finite points can never be a nearest neighbour (d2 is NaN or inf): they get the sentinel key ncell and
 // sort behind every real cell.
 __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
-                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t tag) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     uint32_t key = gp.ncell;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restr
       int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
       key = ((uint32_t)cz * (uint32_t)gp.ny + (uint32_t)cy) * (uint32_t)gp.nxp + (uint32_t)(cx + 1);
     }
-    keys[i] = key;
+    keys[i] = key | tag;  // (tag: the job number of a gang's common sort, above every key bit; else 0)
     vals[i] = (uint32_t)i;
   }
 }
@@ -140,12 +140,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_target_keys(const double *__restr
 // per point on a table far larger than any cache, and ran a three-kernel scan over all of it).
 constexpr int kCtCells = 8192;      // cells per workgroup: tables of millions of cells
 constexpr int kCtCellsSmall = 1024;  // small tables: more workgroups, a short count loop each
-__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ keys, uint32_t n, uint64_t target, int lane) {
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ keys, uint32_t n, uint64_t target, int lane,
+                                                     uint32_t mask) {
   uint32_t lo = 0, hi = n;
   while (hi > lo) {
     const uint32_t step = (hi - lo + 63u) / 64u;
     const uint64_t idx = (uint64_t)lo + (uint64_t)lane * step;
-    const bool pred = idx < hi && (uint64_t)keys[idx] < target;
+    const bool pred = idx < hi && (uint64_t)(keys[idx] & mask) < target;
     const int k = __popcll(__ballot(pred));  // the keys are sorted: pred holds for lanes 0 .. k - 1
     if (k == 0) { hi = lo; break; }
     const uint32_t nlo = lo + (uint32_t)(k - 1) * step + 1u;
@@ -158,14 +159,14 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
 
 template <int kCells>
 __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ cell_start,
-                                                           uint64_t ntab) {
+                                                           uint64_t ntab, uint32_t mask) {
   __shared__ __align__(16) uint32_t cnt[kCells];
   __shared__ uint32_t bounds[2];
   __shared__ uint32_t wsum[O3D_BLOCK / O3D_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t c0 = (uint64_t)blockIdx.x * kCells;
   if (wave < 2) {  // the two ends of the key range, one wavefront each
-    const uint32_t a = wave_lower_bound(keys, n, c0 + (uint64_t)wave * kCells, lane);
+    const uint32_t a = wave_lower_bound(keys, n, c0 + (uint64_t)wave * kCells, lane, mask);
     if (lane == 0) bounds[wave] = a;
   }
   constexpr int kQuads = kCells / (4 * O3D_BLOCK);  // uint4 stores per thread
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
   __syncthreads();
   const uint32_t p0 = bounds[0], p1 = bounds[1];
   if (p1 > p0) {  // (most workgroups of a sparse table own no point and skip this)
-    for (uint32_t p = p0 + tid; p < p1; p += O3D_BLOCK) atomicAdd(&cnt[(uint32_t)((uint64_t)keys[p] - c0)], 1u);
+    for (uint32_t p = p0 + tid; p < p1; p += O3D_BLOCK) atomicAdd(&cnt[(uint32_t)((uint64_t)(keys[p] & mask) - c0)], 1u);
     __syncthreads();
     // exclusive scan in place: each wavefront over its own quarter, 256 cells (one uint4 per lane) at a time
     constexpr int kWaveCells = kCells / (O3D_BLOCK / O3D_WAVE);
@@ -403,9 +404,10 @@ __device__ __forceinline__ uint64_t hilbert3(uint32_t x0, uint32_t x1, uint32_t 
 struct InitT {  // the initial transformation, column-major, as a kernel argument (no upload of its own)
   double m[16];
 };
+template <typename KeyT>  // (uint32_t with a job tag on top: the common sort of a gang)
 __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restrict__ xyz, int64_t n, GridParams gp,
                                                             InitT Tm, int apply, int bits, int drop,
-                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                            KeyT *__restrict__ keys, uint32_t *__restrict__ vals, KeyT tag) {
   const double *T = Tm.m;
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
     double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -418,16 +420,18 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_source_keys(const double *__restr
     int cx = min(max(o3d_cell_coord(x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
     int cy = min(max(o3d_cell_coord(y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
     int cz = min(max(o3d_cell_coord(z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
-    keys[i] = hilbert3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bits) >> drop;
+    keys[i] = (KeyT)(hilbert3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, bits) >> drop) | tag;
     vals[i] = (uint32_t)i;
   }
 }
 
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_source(const double *__restrict__ xyz, const uint32_t *__restrict__ vals,
                                                               int64_t n, double *__restrict__ src_sorted,
-                                                              uint32_t *__restrict__ pos_sorted, float *__restrict__ lb_sorted) {
+                                                              uint32_t *__restrict__ pos_sorted, float *__restrict__ lb_sorted,
+                                                              uint32_t *__restrict__ perm_out) {
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const size_t i = vals[p];
+    if (perm_out) perm_out[p] = (uint32_t)i;  // (the permutation came out of a gang's common sort: keep a copy of our own)
     pos_sorted[p] = 0xFFFFFFFFu;  // no previous match ...
     lb_sorted[p] = 0.f;           // ... and no bound (two memsets less per set-up)
     src_sorted[3 * p] = xyz[3 * i];
@@ -616,20 +620,48 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
     O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    const int key_bits = ceil_log2((uint64_t)gp.ncell + 1);
+    if (o3d_gang_sort *gs = ctx->gang_sort; gs && nfinite > 0 && key_bits <= O3D_GANG_KEY_BITS && gs->jobs.size() < 64 &&
+                                            gs->used + n <= (int64_t)gs->cap) {
+      // the gang sorts for us: keys with our job number on top into its buffer; table and gather wait behind its sort
+      const int64_t off = gs->used;
+      const uint32_t tag = (uint32_t)gs->jobs.size() << O3D_GANG_KEY_BITS;
+      gs->used += n;
+      hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, gs->keys + off, gs->vals + off, tag);
+      O3D_HIP(ctx, hipGetLastError());
+      const size_t ntab_c = ntab;
+      const bool tn_c = want_tn;
+      gs->jobs.push_back({ctx, off, n, [=](const uint32_t *skeys, const uint32_t *svals) -> int {
+        const uint32_t mask = (1u << O3D_GANG_KEY_BITS) - 1u;
+        if (ntab_c > (4u << 20))
+          hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab_c + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
+                             skeys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab_c, mask);
+        else
+          hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab_c + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK),
+                             0, ctx->stream, skeys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab_c, mask);
+        hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm, svals, nfinite, gp,
+                           ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr, ctx->tgt_local, tn_c ? ctx->tn_sorted : nullptr, n);
+        O3D_HIP(ctx, hipGetLastError());
+        return O3D_OK;
+      }});
+      ctx->n_tgt_grid = nfinite;
+      ctx->tn_valid = want_tn ? 1 : 0;
+      return O3D_OK;
+    }
     {  // the keys start in whichever pair of buffers makes the sorted result end in (keys, vals): no copy home
-      const int bits = ceil_log2((uint64_t)gp.ncell + 1);
+      const int bits = key_bits;
       const bool odd = o3d_radix_sort_odd(bits);
       uint32_t *k0 = (uint32_t *)(odd ? tkeys : keys), *v0 = (uint32_t *)(odd ? tvals : vals);
       uint32_t *k1 = (uint32_t *)(odd ? keys : tkeys), *v1 = (uint32_t *)(odd ? vals : tvals);
-      hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, k0, v0);
+      hipLaunchKernelGGL(k_target_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, gp, k0, v0, 0u);
       O3D_TRY(o3d_radix_sort_u32(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
     }
     if (ntab > (4u << 20))
       hipLaunchKernelGGL(k_cell_table<kCtCells>, dim3((unsigned)((ntab + kCtCells - 1) / kCtCells)), dim3(O3D_BLOCK), 0, ctx->stream,
-                         (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+                         (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab, 0xFFFFFFFFu);
     else
       hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK), 0,
-                         ctx->stream, (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab);
+                         ctx->stream, (const uint32_t *)keys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab, 0xFFFFFFFFu);
   }
   ctx->n_tgt_grid = nfinite;
   if (nfinite > 0)
@@ -684,17 +716,33 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   // neighbouring cells of the curve share a key and keep their given order; only the processing ORDER depends on the key).
   const int over = (3 * axis_bits) % 8;
   const int drop = (3 * axis_bits > 8 && over >= 1 && over <= 2) ? over : 0;
+  if (o3d_gang_sort *gs = ctx->gang_sort; gs && 3 * axis_bits - drop <= O3D_GANG_KEY_BITS && gs->jobs.size() < 64 &&
+                                          gs->used + n <= (int64_t)gs->cap) {
+    const int64_t off = gs->used;
+    const uint32_t tag = (uint32_t)gs->jobs.size() << O3D_GANG_KEY_BITS;
+    gs->used += n;
+    hipLaunchKernelGGL(k_source_keys<uint32_t>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, Tm, apply_init, axis_bits,
+                       drop, gs->keys + off, gs->vals + off, tag);
+    O3D_HIP(ctx, hipGetLastError());
+    gs->jobs.push_back({ctx, off, n, [=](const uint32_t *, const uint32_t *svals) -> int {
+      hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, svals, n, ctx->src_sorted, ctx->pos_sorted,
+                         ctx->lb_sorted, ctx->src_perm);
+      O3D_HIP(ctx, hipGetLastError());
+      return O3D_OK;
+    }});
+    return O3D_OK;
+  }
   {  // the permutation must END in src_perm: with an odd number of radix passes it starts in the other buffer (no copy home)
     const int bits = 3 * axis_bits - drop;
     const bool odd = o3d_radix_sort_odd(bits);
     uint64_t *k0 = (uint64_t *)(odd ? tkeys : keys), *k1 = (uint64_t *)(odd ? keys : tkeys);
     uint32_t *v0 = odd ? (uint32_t *)tvals : ctx->src_perm, *v1 = odd ? ctx->src_perm : (uint32_t *)tvals;
-    hipLaunchKernelGGL(k_source_keys, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, Tm, apply_init, axis_bits, drop,
-                       k0, v0);
+    hipLaunchKernelGGL(k_source_keys<uint64_t>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, Tm, apply_init, axis_bits,
+                       drop, k0, v0, (uint64_t)0);
     O3D_TRY(o3d_radix_sort_u64(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
   }
   hipLaunchKernelGGL(k_gather_source, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, (const uint32_t *)ctx->src_perm, n,
-                     ctx->src_sorted, ctx->pos_sorted, ctx->lb_sorted);
+                     ctx->src_sorted, ctx->pos_sorted, ctx->lb_sorted, (uint32_t *)nullptr);
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
 }

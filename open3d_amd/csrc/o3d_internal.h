@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,24 @@ struct IcpState {
   int pad_;
 };
 
+// One radix sort for the set-ups of a whole gang of registrations (o3d_registration_icp_batch): instead of sorting their
+// cell keys themselves -- six short launches per sort, two sorts per registration, most of a small registration's set-up --
+// the slots write their keys, tagged with a job number in the top bits, into one buffer; the gang sorts it once and then
+// runs what each slot had queued behind its sort (cell table and gathers).  A stable sort with the tag on top leaves every
+// job's keys in a segment of their own, in exactly the order its own sort would have produced.
+#define O3D_GANG_KEY_BITS 26  // key bits below the job tag (6 bits: 64 jobs)
+struct o3d_gang_sort {
+  uint32_t *keys = nullptr, *vals = nullptr, *tkeys = nullptr, *tvals = nullptr, *hist = nullptr;
+  size_t cap = 0, hist_cap = 0;  // elements
+  int64_t used = 0;
+  struct Job {
+    struct o3d_ctx *owner;
+    int64_t off, n;
+    std::function<int(const uint32_t *keys, const uint32_t *vals)> then;  // segment pointers of the sorted buffer
+  };
+  std::vector<Job> jobs;
+};
+
 struct o3d_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -106,6 +125,8 @@ struct o3d_ctx {
   void *d_gang = nullptr, *pinned_gang = nullptr;
   int gang_grid = 0, gang_cert = 0, gang_tn = 0;
   int gang_slots = 0;  // > 1: this context is one slot of a gang of that many (set-up sizes its share of the grid)
+  o3d_gang_sort *gang_sort = nullptr;      // where this slot's set-up leaves its sorts (not owned), or null
+  o3d_gang_sort *gang_sort_own = nullptr;  // the gang's sorter, owned by the gang's first context
   double knn_grid_h = -1.0;  // build_knn_grid: the cell size its last trial build was made for
 
   // source shard

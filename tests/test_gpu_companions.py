@@ -410,3 +410,47 @@ def test_batch_gangs_of_unequal_pairs_equal_one_by_one(ctx, oracle, est_name):
                                           max_iter=crit.max_iteration_)
             assert got[k].iterations_ == ref.iterations and np.array_equal(got[k].corr_, ref.corr)
             assert rel_err(got[k].transformation_, ref.transformation) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("est_name", ["p2p", "p2plane"])
+def test_batch_common_sort_equals_sorts_per_pair(ctx, oracle, est_name):
+    """A gang's set-ups leave their two radix sorts to ONE sort over the whole gang's keys (o3d_gang_sort: job number in the
+    key's top bits; the sort is stable, so every pair's segment comes out as its own sort would have left it).  The same
+    batch with O3D_NO_GANG_SORT=1 must agree in every bit -- with non-finite points in a pair, an empty source, and a pair
+    whose cell keys do not fit the common key (it sorts for itself inside the gang)."""
+    import os
+    geometry, reg = _reg()
+    sizes = [(30_000, 28_000), (400, 2_000), (0, 1_500), (18_000, 18_000), (7_000, 9_000), (2_000, 2_000), (25_000, 11_000)]
+    sources, targets = [], []
+    for k, (ns, nt) in enumerate(sizes):
+        sc = make_scene(max(ns, 1), nt, cfg_id=810 + k, L=60.0 if k == 4 else 3.0, theta_deg=0.3)
+        src, tgt = sc["source"][:ns].copy(), sc["target"].copy()
+        nrm = oracle.estimate_normals(tgt, oracle.HYBRID, 30, 0.2 if k != 4 else 4.0)
+        if k == 3:  # non-finite points: skipped by the search, last in their segment of the sort
+            src[5] = np.nan
+            src[1000, 1] = np.inf
+            tgt[7] = np.inf
+        sources.append(geometry.PointCloud(src))
+        targets.append(geometry.PointCloud(tgt, normals=nrm))
+    est = reg.TransformationEstimationPointToPlane() if est_name == "p2plane" else reg.TransformationEstimationPointToPoint()
+    crit = reg.ICPConvergenceCriteria(0.0, 0.0, 8)
+    reg.RegistrationICP(sources[4], targets[4], 0.1, np.eye(4), est, crit, ctx=ctx)
+    info = ctx.grid_info()
+    assert max(info["nx"], info["ny"], info["nz"]) > 256, info  # 27 and more key bits for the source: over the common key
+    os.environ["O3D_BATCH_GANG"] = "4"
+    try:
+        got = reg.RegistrationICPBatch(sources, targets, 0.1, None, est, crit, n_workers=2, want_corr=True, ctx=ctx)
+        os.environ["O3D_NO_GANG_SORT"] = "1"
+        want = reg.RegistrationICPBatch(sources, targets, 0.1, None, est, crit, n_workers=2, want_corr=True, ctx=ctx)
+    finally:
+        os.environ.pop("O3D_BATCH_GANG", None)
+        os.environ.pop("O3D_NO_GANG_SORT", None)
+    for k in range(len(sizes)):
+        assert got[k].iterations_ == want[k].iterations_
+        assert np.array_equal(got[k].corr_, want[k].corr_)
+        assert np.array_equal(got[k].transformation_, want[k].transformation_)
+        assert got[k].fitness_ == want[k].fitness_ and got[k].inlier_rmse_ == want[k].inlier_rmse_
+    ref = oracle.registration_icp(sources[0].points_, targets[0].points_, 0.1, None, 2 if est_name == "p2plane" else 1,
+                                  targets[0].normals_, rel_fitness=0.0, rel_rmse=0.0, max_iter=8)
+    assert np.array_equal(got[0].corr_, ref.corr) and rel_err(got[0].transformation_, ref.transformation) < TOL
