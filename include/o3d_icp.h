@@ -294,6 +294,12 @@ O3D_API int o3d_radius_neighbor_count(o3d_ctx *ctx, const double *xyz, int64_t n
  * cloud statistics and the threshold (:453-466) are a serial pass over these values on the caller's side. */
 O3D_API int o3d_knn_mean_distance(o3d_ctx *ctx, const double *xyz, int64_t n, int nb_neighbors, int mem, double *out_mean);
 
+/* The fast_normal_computation argument of PointCloud::EstimateNormals (PointCloud.h:192, EstimateNormals.cpp:245-251) as a
+ * sticky setting of the context: non-zero (the default, the reference's default) = FastEigen3x3; 0 = column 0 of
+ * Eigen::SelfAdjointEigenSolver<Matrix3d>::compute(covariance, ComputeEigenvectors).eigenvectors(), :247-251.  Read by
+ * o3d_estimate_normals and o3d_estimate_normals_shard on this context (and on every device of a multi context). */
+O3D_API int o3d_set_fast_normal_computation(o3d_ctx *ctx, int fast_normal_computation);
+
 /* EstimateNormals split over GPUs (no counterpart in the reference, whose loop EstimateNormals.cpp:330-350 is
  * per point and independent).  Every rank builds the same grid over the whole cloud; shard g of G computes the normals of
  * positions [g * rows, min(ng, (g + 1) * rows)) of the cell-ordered cloud, rows = ceil(ng / G), ng = number of finite points

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "o3d_debug_copy_bench": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, c_dp]),
     "o3d_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "o3d_set_fast_normal_computation": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                        C.c_int]),
 }

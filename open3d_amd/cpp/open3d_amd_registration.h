@@ -210,8 +210,7 @@ inline std::shared_ptr<o3d_types::PointCloud> VoxelDownSample(const o3d_types::P
 // PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351
 inline void EstimateNormals(o3d_types::PointCloud &cloud, const o3d_types::KDTreeSearchParam &param = o3d_types::KDTreeSearchParamKNN(),
                             bool fast_normal_computation = true, Context &c = Context::Default()) {
-  if (!fast_normal_computation)
-    throw std::runtime_error("open3d_amd: fast_normal_computation=false (Eigen SelfAdjointEigenSolver) is not on the device path");
+  Check(c.get(), o3d_set_fast_normal_computation(c.get(), fast_normal_computation ? 1 : 0));  // :245-251
   const bool has = cloud.HasNormals();
   if (!has) cloud.normals_.resize(cloud.points_.size());
   int type = (int)param.GetSearchType(), knn = 0;

@@ -1533,6 +1533,15 @@ int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_
   return o3d_estimate_normals_impl(ctx, xyz, n, search_type, knn, radius, mem, normals, has_normals);
 }
 
+int o3d_set_fast_normal_computation(o3d_ctx *ctx, int fast_normal_computation) {
+  if (!ctx) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  ctx->normals_fast = fast_normal_computation ? 1 : 0;
+  for (o3d_ctx *r : static_cast<o3d_ctx_full *>(ctx)->ranks)
+    if (r != ctx) r->normals_fast = ctx->normals_fast;
+  return O3D_OK;
+}
+
 int o3d_estimate_normals_shard(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                                const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng) {
   if (!ctx) return O3D_ERR_INVALID_ARG;

@@ -125,6 +125,7 @@ struct o3d_ctx {
   void *d_gang = nullptr, *pinned_gang = nullptr;
   int gang_grid = 0, gang_cert = 0, gang_tn = 0;
   int gang_slots = 0;  // > 1: this context is one slot of a gang of that many (set-up sizes its share of the grid)
+  int normals_fast = 1;                    // EstimateNormals: FastEigen3x3 (1, the reference default) or Eigen's iterative solver (0)
   o3d_gang_sort *gang_sort = nullptr;      // where this slot's set-up leaves its sorts (not owned), or null
   o3d_gang_sort *gang_sort_own = nullptr;  // the gang's sorter, owned by the gang's first context
   double knn_grid_h = -1.0;  // build_knn_grid: the cell size its last trial build was made for

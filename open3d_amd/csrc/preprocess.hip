@@ -223,6 +223,122 @@ __device__ void fast_eigen3x3(const double *cov, double *normal) {
   }
 }
 
+// fast_normal_computation = false (EstimateNormals.cpp:247-251): column 0 of
+// Eigen::SelfAdjointEigenSolver<Matrix3d>::compute(cov, ComputeEigenvectors).eigenvectors() -- the lower triangle scaled by
+// its largest magnitude, the closed-form 3x3 tridiagonalisation, implicit symmetric QR steps with Wilkinson shifts (at most
+// 90), eigenvalues sorted ascending with their columns.  Operation for operation what oracle/o3d_oracle.c
+// (orc_self_adjoint_eigen3x3) restates from Eigen 3.4: the SIGN of the column is whatever that sequence leaves.
+__device__ __forceinline__ void make_givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) { c = p < 0.0 ? -1.0 : 1.0; s = 0.0; }
+  else if (p == 0.0) { c = 0.0; s = q < 0.0 ? 1.0 : -1.0; }
+  else if (fabs(p) > fabs(q)) {
+    const double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0.0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    const double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0.0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+__device__ __forceinline__ double eigen_hypot(double x, double y) {
+  x = fabs(x); y = fabs(y);
+  if (isinf(x) || isinf(y)) return INFINITY;
+  if (isnan(x) || isnan(y)) return NAN;
+  const double p = x > y ? x : y;
+  if (p == 0.0) return 0.0;
+  const double qp = (y < x ? y : x) / p;
+  return p * sqrt(1.0 + qp * qp);
+}
+__device__ void self_adjoint_eigen3_col0(const double *cov, double *normal) {
+  double m00 = cov[0], m10 = cov[3], m11 = cov[4], m20 = cov[6], m21 = cov[7], m22 = cov[8];
+  double scale = fmax(fmax(fmax(fabs(m00), fabs(m10)), fmax(fabs(m20), fabs(m11))), fmax(fabs(m21), fabs(m22)));
+  if (scale == 0.0) scale = 1.0;
+  m00 /= scale; m10 /= scale; m20 /= scale; m11 /= scale; m21 /= scale; m22 /= scale;
+  double d0 = m00, d1, d2, e0, e1;  // diagonal and sub-diagonal
+  double Q[9];                      // column-major
+  const double v1norm2 = m20 * m20;
+  if (v1norm2 <= 2.2250738585072014e-308) {
+    d1 = m11; d2 = m22; e0 = m10; e1 = m21;
+#pragma unroll
+    for (int i = 0; i < 9; i++) Q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    const double beta = sqrt(m10 * m10 + v1norm2);
+    const double inv_beta = 1.0 / beta;
+    const double m01 = m10 * inv_beta, m02 = m20 * inv_beta;
+    const double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+    d1 = m11 + m02 * q;
+    d2 = m22 - m02 * q;
+    e0 = beta;
+    e1 = m21 - m01 * q;
+    Q[0] = 1.0; Q[1] = 0.0; Q[2] = 0.0;
+    Q[3] = 0.0; Q[4] = m01; Q[5] = m02;
+    Q[6] = 0.0; Q[7] = m02; Q[8] = -m01;
+  }
+  double diag[3] = {d0, d1, d2}, sub[2] = {e0, e1};
+  int end = 2, start = 0, iter = 0;
+  const double precision_inv = 1.0 / 2.220446049250313e-16;
+  while (end > 0) {
+    for (int i = start; i < end; i++) {
+      if (fabs(sub[i]) < 2.2250738585072014e-308) sub[i] = 0.0;
+      else {
+        const double scaled = precision_inv * sub[i];
+        if (scaled * scaled <= fabs(diag[i]) + fabs(diag[i + 1])) sub[i] = 0.0;
+      }
+    }
+    while (end > 0 && sub[end - 1] == 0.0) end--;
+    if (end <= 0) break;
+    iter++;
+    if (iter > 90) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0) start--;
+    const double td = (diag[end - 1] - diag[end]) * 0.5;
+    const double e = sub[end - 1];
+    double mu = diag[end];
+    if (td == 0.0) mu -= fabs(e);
+    else if (e != 0.0) {
+      const double e2 = e * e;
+      const double h = eigen_hypot(td, e);
+      if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? h : -h)) / e);
+      else mu -= e2 / (td + (td > 0.0 ? h : -h));
+    }
+    double x = diag[start] - mu;
+    double z = sub[start];
+    for (int k = start; k < end && z != 0.0; k++) {
+      double c, s;
+      make_givens(x, z, c, s);
+      const double sdk = s * diag[k] + c * sub[k];
+      const double dkp1 = s * sub[k] + c * diag[k + 1];
+      diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+      diag[k + 1] = s * sdk + c * dkp1;
+      sub[k] = c * sdk - s * dkp1;
+      if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+      x = sub[k];
+      if (k < end - 1) {
+        z = -s * sub[k + 1];
+        sub[k + 1] = c * sub[k + 1];
+      }
+      if (!(c == 1.0 && s == 0.0)) {
+        for (int r = 0; r < 3; r++) {
+          const double xi = Q[3 * k + r], yi = Q[3 * (k + 1) + r];
+          Q[3 * k + r] = c * xi - s * yi;
+          Q[3 * (k + 1) + r] = s * xi + c * yi;
+        }
+      }
+    }
+  }
+  int col = 0;  // the column the selection sort would bring to the front: the first minimum
+  if (iter <= 90) {
+    if (diag[1] < diag[col]) col = 1;
+    if (diag[2] < diag[col]) col = 2;
+  }
+  normal[0] = Q[3 * col]; normal[1] = Q[3 * col + 1]; normal[2] = Q[3 * col + 2];
+}
+
 constexpr int kNrmBlock = 64;  // one wavefront per workgroup: the k-best lists live in LDS, [slot][lane]
 constexpr int kNrmLoads = 12;  // the LDS lists leave ~1 wavefront per SIMD: memory-level parallelism has to come from the lane
 constexpr int kMaxKnn = 256;  // 8 B per list entry and lane: 128 KiB of the CU's 160 KiB LDS for one wavefront
@@ -478,7 +594,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
                                                                  const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
                                                                  double thr, double *normals, int has_normals, int by_pos,
                                                                  const double *ref, const uint32_t *__restrict__ list,
-                                                                 const uint32_t *__restrict__ list_count) {
+                                                                 const uint32_t *__restrict__ list_count, double *__restrict__ cov_out) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   KList l;
@@ -546,6 +662,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
       }
     }
     double nv[3] = {0.0, 0.0, 1.0};
+    if (cov_out && k < 3) cov_out[7 * oi] = 0.0;  // (k_normals_from_cov writes the (0, 0, 1))
     if (k >= 3) {
       for (int i = 0; i < 9; i++) c[i] /= (double)k;
       double cov[9];
@@ -555,6 +672,11 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
       cov[1] = cov[3] = c[4] - c[0] * c[1];
       cov[2] = cov[6] = c[5] - c[0] * c[2];
       cov[5] = cov[7] = c[7] - c[1] * c[2];
+      if (cov_out) {  // fast_normal_computation = false: the covariance is handed to k_normals_from_cov
+        double *o = cov_out + 7 * oi;
+        o[0] = 1.0; o[1] = cov[0]; o[2] = cov[1]; o[3] = cov[2]; o[4] = cov[4]; o[5] = cov[5]; o[6] = cov[8];
+        continue;
+      }
       fast_eigen3x3(cov, nv);
       if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
         if (has_normals) { nv[0] = ref[3 * qi]; nv[1] = ref[3 * qi + 1]; nv[2] = ref[3 * qi + 2]; }
@@ -564,6 +686,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
         nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0;
       }
     }
+    if (cov_out) continue;
     normals[3 * oi] = nv[0]; normals[3 * oi + 1] = nv[1]; normals[3 * oi + 2] = nv[2];
   }
 }
@@ -629,7 +752,8 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
                                                                       const uint32_t *__restrict__ cell_start, GridParams gp, int knn,
                                                                       double thr, double *normals, int has_normals, int by_pos,
                                                                       const double *ref, uint32_t *__restrict__ fb_list,
-                                                                      uint32_t *__restrict__ fb_count, int knn_only) {
+                                                                      uint32_t *__restrict__ fb_count, int knn_only,
+                                                                      double *__restrict__ cov_out) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary positions
@@ -784,6 +908,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
       }
     }
     double nv[3] = {0.0, 0.0, 1.0};
+    if (cov_out && k < 3) cov_out[7 * oi] = 0.0;  // (k_normals_from_cov writes the (0, 0, 1))
     if (k >= 3) {
       for (int i = 0; i < 9; i++) c[i] /= (double)k;
       double cov[9];
@@ -793,7 +918,38 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
       cov[1] = cov[3] = c[4] - c[0] * c[1];
       cov[2] = cov[6] = c[5] - c[0] * c[2];
       cov[5] = cov[7] = c[7] - c[1] * c[2];
+      if (cov_out) {  // fast_normal_computation = false: the covariance is handed to k_normals_from_cov
+        double *o = cov_out + 7 * oi;
+        o[0] = 1.0; o[1] = cov[0]; o[2] = cov[1]; o[3] = cov[2]; o[4] = cov[4]; o[5] = cov[5]; o[6] = cov[8];
+        continue;
+      }
       fast_eigen3x3(cov, nv);
+      if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
+        if (has_normals) { nv[0] = ref[3 * qi]; nv[1] = ref[3 * qi + 1]; nv[2] = ref[3 * qi + 2]; }
+        else { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
+      }
+      if (has_normals && nv[0] * ref[3 * qi] + nv[1] * ref[3 * qi + 1] + nv[2] * ref[3 * qi + 2] < 0.0) {
+        nv[0] *= -1.0; nv[1] *= -1.0; nv[2] *= -1.0;
+      }
+    }
+    if (cov_out) continue;
+    normals[3 * oi] = nv[0]; normals[3 * oi + 1] = nv[1]; normals[3 * oi + 2] = nv[2];
+  }
+}
+
+// fast_normal_computation = false: the search kernels above leave, per output row, a flag (3 or more neighbours) and the six
+// covariance entries; this finishes the point as they would have (EstimateNormals.cpp:336-349) with Eigen's iterative solver.
+__global__ __launch_bounds__(O3D_BLOCK) void k_normals_from_cov(const double4 *__restrict__ pts, int64_t p_lo, int64_t p_hi,
+                                                                 const double *__restrict__ cov7, double *normals, int has_normals,
+                                                                 int by_pos, const double *ref) {
+  for (int64_t p = p_lo + (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < p_hi; p += (int64_t)gridDim.x * O3D_BLOCK) {
+    const size_t qi = (size_t)__double_as_longlong(pts[p].w);
+    const size_t oi = by_pos ? (size_t)(p - p_lo) : qi;
+    const double *c = cov7 + 7 * oi;
+    double nv[3] = {0.0, 0.0, 1.0};
+    if (c[0] != 0.0) {
+      const double cov[9] = {c[1], c[2], c[3], c[2], c[4], c[5], c[3], c[5], c[6]};
+      self_adjoint_eigen3_col0(cov, nv);
       if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
         if (has_normals) { nv[0] = ref[3 * qi]; nv[1] = ref[3 * qi + 1]; nv[2] = ref[3 * qi + 2]; }
         else { nv[0] = 0.0; nv[1] = 0.0; nv[2] = 1.0; }
@@ -1215,9 +1371,9 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
   const size_t bytes = sizeof(double) * 3 * (size_t)n;
   const double *d_xyz = xyz;
   double *d_nrm = normals;
-  void *sx = nullptr, *sn = nullptr, *sp = nullptr, *sf = nullptr;
+  void *sx = nullptr, *sn = nullptr, *sp = nullptr, *sf = nullptr, *sc = nullptr;
   auto cleanup = [&]() {
-    for (void *b : {sx, sn, sp, sf})
+    for (void *b : {sx, sn, sp, sf, sc})
       if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
@@ -1274,11 +1430,17 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
     g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
     const int by_pos = sharded ? 1 : 0;
     const double *ref = d_nrm;
+    double *d_cov = nullptr;  // fast_normal_computation = false: covariances per output row for k_normals_from_cov
+    if (!ctx->normals_fast && p_hi > p_lo) {
+      const size_t out_rows = sharded ? (size_t)rows : (size_t)n;
+      O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sc, sizeof(double) * 7 * std::max<size_t>(out_rows, 1)));
+      d_cov = (double *)sc;
+    }
     if (p_hi > p_lo) {
       if (degenerate) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+                           ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
       } else if (knn_hist) {
         O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
         uint32_t *fb_list = (uint32_t *)sf + 64, *fb_count = (uint32_t *)sf;
@@ -1288,19 +1450,19 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         const size_t hlds = hist_lds_bytes(kk);
         O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
         hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr_knn, d_out, has_normals, by_pos, ref, fb_list, fb_count, 1);
+                           ctx->cell_start, ctx->gp, kk, thr_knn, d_out, has_normals, by_pos, ref, fb_list, fb_count, 1, d_cov);
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 4)), dim3(kNrmBlock), lds, ctx->stream,
                            ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,
-                           (const uint32_t *)fb_list, (const uint32_t *)fb_count);
+                           (const uint32_t *)fb_list, (const uint32_t *)fb_count, d_cov);
       } else if (search_type == O3D_SEARCH_KNN) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
       } else if (search_type == O3D_SEARCH_RADIUS) {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<1>, lds));
         hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
       } else if (kk <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP")) {
         // hybrid: selection by counting (k_estimate_normals_hist); what does not fit it is left on a list for the heap kernel
         O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
@@ -1309,17 +1471,20 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         const size_t hlds = hist_lds_bytes(kk);
         O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
         hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count, 0);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count, 0, d_cov);
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 2)), dim3(kNrmBlock), lds, ctx->stream,
                            ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,
-                           (const uint32_t *)fb_list, (const uint32_t *)fb_count);
+                           (const uint32_t *)fb_list, (const uint32_t *)fb_count, d_cov);
       } else {
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr);
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
       }
     }
+    if (d_cov)
+      hipLaunchKernelGGL(k_normals_from_cov, dim3(grid_for(p_hi - p_lo)), dim3(O3D_BLOCK), 0, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                         (const double *)d_cov, d_out, has_normals, by_pos, ref);
     if (!sharded && ng < n) hipLaunchKernelGGL(k_normals_nonfinite, dim3(grid_for(n)), dim3(O3D_BLOCK), 0, ctx->stream, d_xyz, n, d_nrm);
     O3D_HIP(ctx, hipGetLastError());
     if (mem == O3D_MEM_HOST) {

@@ -86,11 +86,10 @@ class PointCloud:
         return (out, ov[:m]) if return_voxel_index else out
 
     def EstimateNormals(self, search_param=None, fast_normal_computation=True, ctx=None):
-        """PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351."""
-        if not fast_normal_computation:
-            raise _lib.O3DError(_lib.load().o3d_status_string(9) and 9,
-                                "fast_normal_computation=False (Eigen SelfAdjointEigenSolver) is not on the device path")
+        """PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351 (fast_normal_computation=False: Eigen's
+        SelfAdjointEigenSolver instead of FastEigen3x3, :245-251)."""
         ctx = ctx or _lib.default_context()
+        ctx.check(ctx._lib.o3d_set_fast_normal_computation(ctx.handle, int(bool(fast_normal_computation))))
         sp = search_param or KDTreeSearchParamKNN()
         n = len(self.points_)
         has = self.HasNormals()

@@ -183,10 +183,11 @@ class HipNormalsEngine:
         self._lib = _lib
         self.ctx = ctx or _lib.default_context()
 
-    def shard(self, points, normals, search_param, shard, n_shards):
+    def shard(self, points, normals, search_param, shard, n_shards, fast_normal_computation=True):
         """-> (part rows x 3 float64, ng)."""
         import ctypes as C
         lib, c = self._lib, self.ctx
+        c.check(c._lib.o3d_set_fast_normal_computation(c.handle, int(bool(fast_normal_computation))))
         n = len(points)
         rows = (n + n_shards - 1) // n_shards  # upper bound of ceil(ng / n_shards): ng <= n
         part = np.zeros((max(rows, 1), 3))
@@ -222,10 +223,13 @@ class ShardedNormals:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else torch.device("cpu")
 
-    def run(self, cloud, search_param):
+    def run(self, cloud, search_param, fast_normal_computation=True):
         pts = np.ascontiguousarray(cloud.points_, dtype=np.float64)
         ref = np.ascontiguousarray(cloud.normals_, dtype=np.float64) if cloud.HasNormals() else None
-        part, ng = self.engine.shard(pts, ref, search_param, self.rank, self.world)
+        if fast_normal_computation:  # (engines injected by the CPU tests know only the default)
+            part, ng = self.engine.shard(pts, ref, search_param, self.rank, self.world)
+        else:
+            part, ng = self.engine.shard(pts, ref, search_param, self.rank, self.world, fast_normal_computation=False)
         rows = part.shape[0]  # ceil(ng / world): the same on every rank
         t = self.torch.from_numpy(np.ascontiguousarray(part)).to(self.device)
         if self.world > 1:

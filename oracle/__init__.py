@@ -343,16 +343,17 @@ def voxel_down_sample(pts, voxel, normals=None, colors=None):
 KNN, RADIUS, HYBRID = 0, 1, 2
 
 
-def estimate_normals(pts, search_type=KNN, knn=30, radius=0.0, normals=None, want_counts=False):
-    """EstimateNormals.cpp:320-351 -> normals [n,3] (and neighbour counts)."""
+def estimate_normals(pts, search_type=KNN, knn=30, radius=0.0, normals=None, want_counts=False, fast=True):
+    """EstimateNormals.cpp:320-351 -> normals [n,3] (and neighbour counts).  fast=False: fast_normal_computation=false,
+    Eigen's SelfAdjointEigenSolver (:247-251)."""
     pts = _pts(pts)
     n = len(pts)
     has = normals is not None
     out = _pts(normals).copy() if has else np.zeros((n, 3))
     cnt = np.zeros(n, np.int32)
     if n:
-        lib().orc_estimate_normals(_d(pts), C.c_int64(n), int(search_type), int(knn), C.c_double(radius), _d(out), int(has),
-                                   _i(cnt))
+        fn = lib().orc_estimate_normals if fast else lib().orc_estimate_normals_eigen
+        fn(_d(pts), C.c_int64(n), int(search_type), int(knn), C.c_double(radius), _d(out), int(has), _i(cnt))
     return (out, cnt) if want_counts else out
 
 
@@ -375,6 +376,17 @@ def compute_normal(pts, indices):
     cov = np.zeros(9)
     lib().orc_compute_normal(_d(pts), _i(indices), len(indices), _d(nv), _d(cov))
     return nv, cov.reshape(3, 3)
+
+
+def self_adjoint_eigen3x3(cov):
+    """Eigen::SelfAdjointEigenSolver<Matrix3d>::compute as restated in the oracle -> (eigenvalues ascending, eigenvectors as
+    columns, converged)."""
+    cov = np.ascontiguousarray(cov, np.float64).reshape(3, 3)
+    ev = np.zeros(3)
+    q = np.zeros(9)
+    lib().orc_self_adjoint_eigen3x3.restype = C.c_int
+    ok = lib().orc_self_adjoint_eigen3x3(_d(cov), _d(ev), _d(q))
+    return ev, q.reshape(3, 3).T.copy(), bool(ok)
 
 
 def fast_eigen3x3(cov):

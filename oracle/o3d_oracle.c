@@ -1381,9 +1381,156 @@ ORC_EXPORT void orc_fast_eigen3x3(const double *cov_rowmajor, double *normal) { 
   }
 }
 
-/* ComputeNormal :215-252 (fast path only: fast_normal_computation=true is the
- * reference default, PointCloud.h:192).  Returns the covariance too. */
+/* fast_normal_computation = false, EstimateNormals.cpp:247-251:
+ *   Eigen::SelfAdjointEigenSolver<Eigen::Matrix3d> solver; solver.compute(covariance, ComputeEigenvectors);
+ *   return solver.eigenvectors().col(0);
+ * Eigen is not in the container: restated FROM MEMORY of Eigen 3.4.0, parity unpinned --
+ *   SelfAdjointEigenSolver::compute            lower triangle, scaled by its largest |coefficient| (a division each)
+ *   tridiagonalization_inplace_selector<,3>    the closed form for 3x3 (one Householder-like reflection, Q = [1 0 0; 0 m01 m02; 0 m02 -m01])
+ *   computeFromTridiagonal_impl                deflation test (|e| / eps)^2 <= |d_i| + |d_i+1|, at most 30 * 3 sweeps,
+ *                                              then selection sort of the eigenvalues (first minimum), columns swapped along
+ *   tridiagonal_qr_step                        Wilkinson shift (numext::hypot = p * sqrt(1 + (q/p)^2)), Givens chase,
+ *                                              Q.applyOnTheRight(k, k + 1, rot)
+ *   JacobiRotation::makeGivens                 the real-scalar branch.
+ * The sign of the returned column is whatever this sequence of operations leaves; the caller does not normalise it. */
+static void orc_make_givens(double p, double q, double *c, double *s) {
+  if (q == 0.0) { *c = p < 0.0 ? -1.0 : 1.0; *s = 0.0; }
+  else if (p == 0.0) { *c = 0.0; *s = q < 0.0 ? 1.0 : -1.0; }
+  else if (fabs(p) > fabs(q)) {
+    double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0.0) u = -u;
+    *c = 1.0 / u;
+    *s = -t * *c;
+  } else {
+    double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0.0) u = -u;
+    *s = -1.0 / u;
+    *c = -t * *s;
+  }
+}
+static double orc_eigen_hypot(double x, double y) { /* numext::hypot -> positive_real_hypot(|x|, |y|) */
+  x = fabs(x); y = fabs(y);
+  if (isinf(x) || isinf(y)) return INFINITY;
+  if (isnan(x) || isnan(y)) return NAN;
+  double p = x > y ? x : y;   /* numext::maxi(x, y) */
+  if (p == 0.0) return 0.0;
+  double qp = (y < x ? y : x) / p;
+  return p * sqrt(1.0 + qp * qp);
+}
+/* eivals[3] ascending, eivecs column-major (eivecs[3 * c + r]); returns 0 when the iteration did not converge */
+ORC_EXPORT int orc_self_adjoint_eigen3x3(const double *cov_rowmajor, double *eivals, double *eivecs) {
+  double m00 = cov_rowmajor[0], m10 = cov_rowmajor[3], m11 = cov_rowmajor[4];
+  double m20 = cov_rowmajor[6], m21 = cov_rowmajor[7], m22 = cov_rowmajor[8];
+  /* cwiseAbs().maxCoeff() of the lower triangle (column-major visit; the order does not matter for a maximum) */
+  double scale = fabs(m00);
+  if (fabs(m10) > scale) scale = fabs(m10);
+  if (fabs(m20) > scale) scale = fabs(m20);
+  if (fabs(m11) > scale) scale = fabs(m11);
+  if (fabs(m21) > scale) scale = fabs(m21);
+  if (fabs(m22) > scale) scale = fabs(m22);
+  if (scale == 0.0) scale = 1.0;
+  m00 /= scale; m10 /= scale; m20 /= scale; m11 /= scale; m21 /= scale; m22 /= scale;
+  double diag[3], sub[2], Q[9]; /* Q column-major */
+  const double tol = DBL_MIN;
+  diag[0] = m00;
+  double v1norm2 = m20 * m20;
+  if (v1norm2 <= tol) {
+    diag[1] = m11; diag[2] = m22; sub[0] = m10; sub[1] = m21;
+    for (int i = 0; i < 9; i++) Q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    double beta = sqrt(m10 * m10 + v1norm2);
+    double invBeta = 1.0 / beta;
+    double m01 = m10 * invBeta, m02 = m20 * invBeta;
+    double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+    diag[1] = m11 + m02 * q;
+    diag[2] = m22 - m02 * q;
+    sub[0] = beta;
+    sub[1] = m21 - m01 * q;
+    Q[0] = 1; Q[1] = 0; Q[2] = 0;      /* column 0 */
+    Q[3] = 0; Q[4] = m01; Q[5] = m02;  /* column 1 */
+    Q[6] = 0; Q[7] = m02; Q[8] = -m01; /* column 2 */
+  }
+  const int n = 3, max_iter = 30;
+  int end = n - 1, start = 0, iter = 0;
+  const double precision_inv = 1.0 / DBL_EPSILON;
+  while (end > 0) {
+    for (int i = start; i < end; i++) {
+      if (fabs(sub[i]) < DBL_MIN) sub[i] = 0.0;
+      else {
+        double scaled = precision_inv * sub[i];
+        if (scaled * scaled <= fabs(diag[i]) + fabs(diag[i + 1])) sub[i] = 0.0;
+      }
+    }
+    while (end > 0 && sub[end - 1] == 0.0) end--;
+    if (end <= 0) break;
+    iter++;
+    if (iter > max_iter * n) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0) start--;
+    { /* tridiagonal_qr_step(diag, sub, start, end, Q, n) */
+      double td = (diag[end - 1] - diag[end]) * 0.5;
+      double e = sub[end - 1];
+      double mu = diag[end];
+      if (td == 0.0) mu -= fabs(e);
+      else if (e != 0.0) {
+        double e2 = e * e;
+        double h = orc_eigen_hypot(td, e);
+        if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? h : -h)) / e);
+        else mu -= e2 / (td + (td > 0.0 ? h : -h));
+      }
+      double x = diag[start] - mu;
+      double z = sub[start];
+      for (int k = start; k < end && z != 0.0; k++) {
+        double c, s;
+        orc_make_givens(x, z, &c, &s);
+        double sdk = s * diag[k] + c * sub[k];
+        double dkp1 = s * sub[k] + c * diag[k + 1];
+        diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+        diag[k + 1] = s * sdk + c * dkp1;
+        sub[k] = c * sdk - s * dkp1;
+        if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+        x = sub[k];
+        if (k < end - 1) {
+          z = -s * sub[k + 1];
+          sub[k + 1] = c * sub[k + 1];
+        }
+        if (!(c == 1.0 && s == 0.0)) /* apply_rotation_in_the_plane returns early on the identity */
+          for (int r = 0; r < 3; r++) {
+            double xi = Q[3 * k + r], yi = Q[3 * (k + 1) + r];
+            Q[3 * k + r] = c * xi - s * yi;
+            Q[3 * (k + 1) + r] = s * xi + c * yi;
+          }
+      }
+    }
+  }
+  int ok = iter <= max_iter * n;
+  if (ok) {
+    for (int i = 0; i < n - 1; i++) {
+      int k = 0;
+      for (int j = 1; j < n - i; j++) if (diag[i + j] < diag[i + k]) k = j;
+      if (k > 0) {
+        double t = diag[i]; diag[i] = diag[k + i]; diag[k + i] = t;
+        for (int r = 0; r < 3; r++) { t = Q[3 * i + r]; Q[3 * i + r] = Q[3 * (k + i) + r]; Q[3 * (k + i) + r] = t; }
+      }
+    }
+  }
+  for (int i = 0; i < 3; i++) eivals[i] = diag[i] * scale;
+  memcpy(eivecs, Q, sizeof Q);
+  return ok;
+}
+
+/* ComputeNormal :215-252 (fast_normal_computation=true is the reference default, PointCloud.h:192).
+ * Returns the covariance too. */
+static void orc_compute_normal_impl(const double *pts, const int *indices, int k, double *normal, double *cov_out, int fast);
 ORC_EXPORT void orc_compute_normal(const double *pts, const int *indices, int k, double *normal, double *cov_out) {
+  orc_compute_normal_impl(pts, indices, k, normal, cov_out, 1);
+}
+ORC_EXPORT void orc_compute_normal_eigen(const double *pts, const int *indices, int k, double *normal, double *cov_out) {
+  orc_compute_normal_impl(pts, indices, k, normal, cov_out, 0);
+}
+static void orc_compute_normal_impl(const double *pts, const int *indices, int k, double *normal, double *cov_out, int fast) {
   if (k == 0) { normal[0] = normal[1] = normal[2] = 0; return; }
   double c[9] = {0};
   for (int i = 0; i < k; i++) {
@@ -1401,14 +1548,30 @@ ORC_EXPORT void orc_compute_normal(const double *pts, const int *indices, int k,
   cov[2] = cov[6] = c[5] - c[0] * c[2];
   cov[5] = cov[7] = c[7] - c[1] * c[2];
   if (cov_out) memcpy(cov_out, cov, sizeof cov);
-  orc_fast_eigen3x3(cov, normal);
+  if (fast) orc_fast_eigen3x3(cov, normal);
+  else {
+    double ev[3], Q[9];
+    orc_self_adjoint_eigen3x3(cov, ev, Q);
+    normal[0] = Q[0]; normal[1] = Q[1]; normal[2] = Q[2];
+  }
 }
 
 /* PointCloud::EstimateNormals :320-351.  search_type: 0 = KNN, 1 = Radius,
  * 2 = Hybrid (KDTreeSearchParam.h:35-107).  normals is in/out when has_normals.
  * nn_count (nullable) receives the neighbour count per point. */
+static void orc_estimate_normals_impl(const double *pts, int64_t n, int search_type, int knn, double radius,
+                                      double *normals, int has_normals, int32_t *nn_count, int fast);
 ORC_EXPORT void orc_estimate_normals(const double *pts, int64_t n, int search_type, int knn, double radius,
                                      double *normals, int has_normals, int32_t *nn_count) {
+  orc_estimate_normals_impl(pts, n, search_type, knn, radius, normals, has_normals, nn_count, 1);
+}
+/* ... with fast_normal_computation = false */
+ORC_EXPORT void orc_estimate_normals_eigen(const double *pts, int64_t n, int search_type, int knn, double radius,
+                                           double *normals, int has_normals, int32_t *nn_count) {
+  orc_estimate_normals_impl(pts, n, search_type, knn, radius, normals, has_normals, nn_count, 0);
+}
+static void orc_estimate_normals_impl(const double *pts, int64_t n, int search_type, int knn, double radius,
+                                      double *normals, int has_normals, int32_t *nn_count, int fast) {
   orc_kdtree *kd = orc_kdtree_build(pts, n);
 #ifdef _OPENMP
 #pragma omp parallel
@@ -1431,7 +1594,7 @@ ORC_EXPORT void orc_estimate_normals(const double *pts, int64_t n, int search_ty
       if (nn_count) nn_count[i] = k;
       double nv[3];
       if (k >= 3) {
-        orc_compute_normal(pts, use, k, nv, NULL);
+        orc_compute_normal_impl(pts, use, k, nv, NULL, fast);
         if (sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]) == 0.0) {
           if (has_normals) { nv[0] = normals[3 * i]; nv[1] = normals[3 * i + 1]; nv[2] = normals[3 * i + 2]; }
           else { nv[0] = 0; nv[1] = 0; nv[2] = 1; }

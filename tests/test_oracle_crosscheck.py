@@ -419,3 +419,35 @@ def test_feature_nearest_and_checkers_against_numpy(oracle):
         assert oracle.ransac_check(src, tgt, c, T, normal_angle=1.4)   # no normals: passes (:67-72)
         seen += [edge, dist, nrm]
     assert np.all(seen > 0) and np.all(seen < 300)   # every checker gave both answers
+
+
+def test_self_adjoint_eigen_solver_restatement(oracle):
+    """The oracle's restatement of Eigen::SelfAdjointEigenSolver<Matrix3d> (fast_normal_computation=false,
+    EstimateNormals.cpp:247-251; Eigen itself is absent: parity unpinned) against numpy's eigh: eigenvalues to rounding,
+    eigenvectors orthonormal with A v = w v, ascending order; and the solver's fixed points."""
+    rng = np.random.default_rng(0)
+    for t in range(4000):
+        a = rng.standard_normal((3, 3)) * 10 ** rng.uniform(-6, 3)
+        kind = t % 5
+        if kind == 1:
+            a[:, 2] *= 1e-6
+        if kind == 2:
+            a = np.diag(rng.standard_normal(3))
+        if kind == 3:
+            a[2] = a[1]
+        A = a @ a.T
+        ev, Q, ok = oracle.self_adjoint_eigen3x3(A)
+        w = np.linalg.eigvalsh(A)
+        sc = max(np.abs(w).max(), 1e-300)
+        assert ok and np.all(np.diff(ev) >= 0)
+        assert np.abs(ev - w).max() / sc < 1e-13
+        assert np.abs(A @ Q - Q * ev).max() / sc < 1e-13
+        assert np.abs(Q.T @ Q - np.eye(3)).max() < 1e-13
+    ev, Q, ok = oracle.self_adjoint_eigen3x3(np.zeros((3, 3)))
+    assert ok and np.array_equal(ev, [0, 0, 0]) and np.array_equal(Q, np.eye(3))
+    ev, Q, ok = oracle.self_adjoint_eigen3x3(np.diag([3.0, 1.0, 2.0]))
+    assert np.array_equal(ev, [1, 2, 3]) and np.array_equal(Q[:, 0], [0, 1, 0])
+    # a normal through ComputeNormal with the solver: a plane z = 0 gives +-(0, 0, 1)
+    pts = np.concatenate([rng.random((40, 2)), np.zeros((40, 1))], axis=1)
+    n_eig = oracle.estimate_normals(pts, oracle.KNN, 10, 0.0, fast=False)
+    assert np.allclose(np.abs(n_eig[:, 2]), 1.0, atol=1e-12)
