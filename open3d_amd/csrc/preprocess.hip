@@ -1296,6 +1296,97 @@ __global__ __launch_bounds__(kNrmBlock) void k_fpfh(const double4 *__restrict__ 
   }
 }
 
+// ComputeFPFHFeature with a radius search parameter (KDTreeSearchParamRadius: EVERY point with d2 < thr, Feature.cpp:83,131):
+// no list -- the 3x3x3 block is walked once per pass and every neighbour is used as it comes.
+//   PASS 0: the neighbours' three bins are COUNTED (per-lane counters in LDS, [bin][lane]); a histogram entry of the
+//           reference is hist_incr added once per neighbour of the bin, whatever their order, so it is rebuilt by that many
+//           additions afterwards.  The reference leaves out element 0 of the sorted list: the query itself, or a duplicate of
+//           it with a lower index -- the same thing to ComputePairFeatures (distance 0 -> all zero) -- so the query's own
+//           position is the one left out here.  nbr_cnt[p] keeps the number of neighbours.
+//   PASS 1: the weighted sum over the neighbours in the order of the walk (the reference adds them by ascending distance:
+//           the same terms, rounding-level difference in the sum).
+template <int PASS>
+__global__ __launch_bounds__(kNrmBlock) void k_fpfh_radius(const double4 *__restrict__ pts, int64_t n_grid,
+                                                            const uint32_t *__restrict__ cell_start, GridParams gp, double thr,
+                                                            const double *__restrict__ normals, const double *__restrict__ spfh,
+                                                            double *__restrict__ out) {
+  __shared__ uint32_t bins[33][kNrmBlock];
+  const int lane = threadIdx.x;
+  for (int64_t p = (int64_t)blockIdx.x * kNrmBlock + lane; p < n_grid; p += (int64_t)gridDim.x * kNrmBlock) {
+    const double4 q = pts[p];
+    const size_t qi = (size_t)__double_as_longlong(q.w);
+    const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
+    const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
+    const int cz = min(max(o3d_cell_coord(q.z, gp.gmin[2], gp.inv_h, gp.nz), 0), gp.nz - 1);
+    double *o = out + 33 * qi;
+    if (PASS == 0) {
+#pragma unroll
+      for (int b = 0; b < 33; b++) bins[b][lane] = 0u;
+      const double p1[3] = {q.x, q.y, q.z};
+      const double n1[3] = {normals[3 * qi], normals[3 * qi + 1], normals[3 * qi + 2]};
+      uint32_t others = 0;
+      auto visit = [&](const double4 &t, uint32_t j, bool real) {
+        const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+        double d2 = ddx * ddx;
+        d2 = d2 + ddy * ddy;
+        d2 = d2 + ddz * ddz;
+        if (!real || j == (uint32_t)p || !(d2 < thr)) return;
+        others++;
+        const size_t ti = (size_t)__double_as_longlong(t.w);
+        const double p2[3] = {t.x, t.y, t.z};
+        const double n2[3] = {normals[3 * ti], normals[3 * ti + 1], normals[3 * ti + 2]};
+        double f[4];
+        pair_features(p1, n1, p2, n2, f);
+        bins[fpfh_bin(11 * (f[0] + M_PI) / (2.0 * M_PI))][lane]++;
+        bins[fpfh_bin(11 * (f[1] + 1.0) * 0.5) + 11][lane]++;
+        bins[fpfh_bin(11 * (f[2] + 1.0) * 0.5) + 22][lane]++;
+      };
+      walk_block3(pts, cell_start, gp, cx, cy, cz, (uint32_t)p, visit);
+      if (others > 0) {  // (the row was zeroed by the host)
+        const double hist_incr = 100.0 / (double)others;
+        for (int b = 0; b < 33; b++) {
+          double v = 0.0;
+          for (uint32_t c = bins[b][lane]; c > 0; c--) v += hist_incr;
+          o[b] = v;
+        }
+      }
+    } else {
+      double acc[33], sum[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < 33; j++) acc[j] = 0.0;
+      uint32_t others = 0;
+      auto visit = [&](const double4 &t, uint32_t j, bool real) {
+        const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
+        double d2 = ddx * ddx;
+        d2 = d2 + ddy * ddy;
+        d2 = d2 + ddz * ddz;
+        if (!real || j == (uint32_t)p || !(d2 < thr)) return;
+        others++;
+        if (d2 == 0.0) return;
+        const double *sp = spfh + 33 * (size_t)__double_as_longlong(t.w);
+#pragma unroll
+        for (int b = 0; b < 33; b++) {
+          const double val = sp[b] / d2;
+          sum[b / 11] += val;
+          acc[b] += val;
+        }
+      };
+      walk_block3(pts, cell_start, gp, cx, cy, cz, (uint32_t)p, visit);
+      if (others > 0) {
+        for (int j = 0; j < 3; j++)
+          if (sum[j] != 0.0) sum[j] = 100.0 / sum[j];
+        const double *self = spfh + 33 * qi;
+#pragma unroll
+        for (int j = 0; j < 33; j++) {
+          double v = acc[j] * sum[j / 11];
+          v += self[j];
+          o[j] = v;
+        }
+      }
+    }
+  }
+}
+
 // Non-finite points are not in the grid: FLANN finds no finite-distance neighbour for them -> fewer than 3 -> (0,0,1).
 __global__ __launch_bounds__(O3D_BLOCK) void k_normals_nonfinite(const double *__restrict__ xyz, int64_t n, double *__restrict__ normals) {
   for (int64_t i = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -1763,9 +1854,10 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
   if (n < 0 || (n > 0 && (!xyz || !out_feature))) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "ComputeFPFHFeature: null buffer");
   if (!nrm && n > 0)
     return o3d_fail(ctx, O3D_ERR_NEED_NORMALS, "[Open3D ERROR] [ComputeFPFHFeature] Failed because input point cloud has no normal.");
-  if (search_type != O3D_SEARCH_KNN && search_type != O3D_SEARCH_HYBRID)
-    return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: only KNN and hybrid search parameters are on the device path");
-  if (knn > kMaxKnn) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: knn/max_nn > %d is not on the device path", kMaxKnn);
+  if (search_type != O3D_SEARCH_KNN && search_type != O3D_SEARCH_HYBRID && search_type != O3D_SEARCH_RADIUS)
+    return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "ComputeFPFHFeature: unknown search parameter type %d", search_type);
+  const bool radius_mode = search_type == O3D_SEARCH_RADIUS;
+  if (!radius_mode && knn > kMaxKnn) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: knn/max_nn > %d is not on the device path", kMaxKnn);
   if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "ComputeFPFHFeature: more than 2^31-1 points");
   if (n == 0) return O3D_OK;
   ctx->icp_ready = 0;
@@ -1790,7 +1882,7 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
     O3D_HIP(ctx, hipMemsetAsync(sp, 0, fbytes, ctx->stream));
     O3D_HIP(ctx, hipMemsetAsync(d_out, 0, fbytes, ctx->stream));
     const bool knn_mode = search_type == O3D_SEARCH_KNN;
-    if (knn < 1 || (!knn_mode && !(radius > 0.0))) {  // no point has a neighbour besides (at most) itself: all zero
+    if ((!radius_mode && knn < 1) || (!knn_mode && !(radius > 0.0))) {  // no point has a neighbour besides (at most) itself: all zero
       if (mem == O3D_MEM_HOST) O3D_HIP(ctx, o3d_d2h(ctx, out_feature, d_out, fbytes));
       O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
       return O3D_OK;
@@ -1799,7 +1891,16 @@ int o3d_fpfh_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, int64_t n,
     if (knn_mode) O3D_TRY(build_knn_grid(ctx, d_xyz, n, &h));
     else O3D_TRY(o3d_build_target_grid(ctx, d_xyz, nullptr, n, radius, 1));
     const int64_t ng = ctx->n_tgt_grid;
-    if (ng > 0) {
+    if (ng > 0 && radius_mode) {
+      const double thr = (double)(float)(radius * radius);  // KDTreeFlann.cpp:126
+      int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;
+      g = std::max<int64_t>(1, std::min<int64_t>(g, O3D_NUM_CU * 24));
+      hipLaunchKernelGGL(k_fpfh_radius<0>, dim3((int)g), dim3(kNrmBlock), 0, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp,
+                         thr, d_nrm, (const double *)nullptr, (double *)sp);
+      hipLaunchKernelGGL(k_fpfh_radius<1>, dim3((int)g), dim3(kNrmBlock), 0, ctx->stream, ctx->tgt_sorted, ng, ctx->cell_start, ctx->gp,
+                         thr, d_nrm, (const double *)sp, d_out);
+      O3D_HIP(ctx, hipGetLastError());
+    } else if (ng > 0) {
       const double thr = (double)(float)(radius * radius);
       const size_t lds = kListEntryBytes * kNrmBlock * (size_t)knn;
       int64_t g = (ng + kNrmBlock - 1) / kNrmBlock;

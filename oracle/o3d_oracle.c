@@ -1085,7 +1085,13 @@ static int fpfh_bin(double v) {
   return h < 0 ? 0 : (h >= 11 ? 10 : h);
 }
 
-static int fpfh_search(const orc_kdtree *kd, const double *q, int search_type, int knn, double radius, int *idx, double *d2) {
+/* KDTreeFlann::Search (KDTreeFlann.cpp:75-91) by parameter type; a radius search (type 1) returns its own arrays in
+ * *ridx / *rd2 (ascending distance, to be freed by the caller), the others fill idx / d2 */
+static int fpfh_search(const orc_kdtree *kd, const double *q, int search_type, int knn, double radius, int *idx, double *d2,
+                       int **ridx, double **rd2) {
+  *ridx = NULL; *rd2 = NULL;
+  if (search_type == 1) return orc_kdtree_search_radius(kd, q, radius, ridx, rd2);
+  if (knn <= 0) return 0;
   return search_type == 0 ? orc_kdtree_search_knn(kd, q, knn, idx, d2) : orc_kdtree_search_hybrid(kd, q, radius, knn, idx, d2);
 }
 
@@ -1106,32 +1112,38 @@ ORC_EXPORT void orc_fpfh(const double *pts, const double *nrm, int64_t n, int se
 #pragma omp for schedule(static)
 #endif
     for (int64_t i = 0; i < n; i++) { /* ComputeSPFHFeature :78-109 */
-      const int k = knn > 0 ? fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2) : 0;
+      int *ri; double *rd;
+      const int k = fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2, &ri, &rd);
+      const int *use = ri ? ri : idx;
       if (k > 1) {
         const double hist_incr = 100.0 / (double)(k - 1);
         double *o = spfh + 33 * i;
         for (int j = 1; j < k; j++) {
           double f[4];
-          pair_features(pts + 3 * i, nrm + 3 * i, pts + 3 * (size_t)idx[j], nrm + 3 * (size_t)idx[j], f);
+          pair_features(pts + 3 * i, nrm + 3 * i, pts + 3 * (size_t)use[j], nrm + 3 * (size_t)use[j], f);
           o[fpfh_bin(11 * (f[0] + kPi) / (2.0 * kPi))] += hist_incr;
           o[fpfh_bin(11 * (f[1] + 1.0) * 0.5) + 11] += hist_incr;
           o[fpfh_bin(11 * (f[2] + 1.0) * 0.5) + 22] += hist_incr;
         }
       }
+      free(ri); free(rd);
     }
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
     for (int64_t i = 0; i < n; i++) { /* :127-157 */
-      const int k = knn > 0 ? fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2) : 0;
+      int *ri; double *rd;
+      const int k = fpfh_search(kd, pts + 3 * i, search_type, knn, radius, idx, d2, &ri, &rd);
+      const int *use = ri ? ri : idx;
+      const double *used2 = rd ? rd : d2;
       if (k > 1) {
         double sum[3] = {0.0, 0.0, 0.0};
         double *o = feature + 33 * i;
         for (int j = 1; j < k; j++) {
-          const double dist = d2[j];
+          const double dist = used2[j];
           if (dist == 0.0) continue;
           for (int b = 0; b < 33; b++) {
-            const double val = spfh[33 * (size_t)idx[j] + b] / dist;
+            const double val = spfh[33 * (size_t)use[j] + b] / dist;
             sum[b / 11] += val;
             o[b] += val;
           }
@@ -1143,6 +1155,7 @@ ORC_EXPORT void orc_fpfh(const double *pts, const double *nrm, int64_t n, int se
           o[b] += spfh[33 * i + b];
         }
       }
+      free(ri); free(rd);
     }
     free(idx);
     free(d2);

@@ -203,7 +203,7 @@ def test_outlier_removal_matches_oracle(ctx, oracle):
     assert len(geometry.PointCloud().RemoveStatisticalOutliers(5, 1.0, ctx=ctx)[1]) == 0
 
 
-@pytest.mark.parametrize("mode", ["knn", "hybrid"])
+@pytest.mark.parametrize("mode", ["knn", "hybrid", "radius"])
 def test_fpfh_matches_oracle(ctx, oracle, mode):
     """ComputeFPFHFeature (Feature.cpp:113-159).  Same neighbour lists and summation order as the oracle; histogram bins
     come from acos / atan2 / sqrt of the device's libm, which may differ from the host's in the last ulp, so a bin can flip
@@ -217,9 +217,27 @@ def test_fpfh_matches_oracle(ctx, oracle, mode):
     pc = geometry.PointCloud(pts, normals=nrm)
     if mode == "knn":
         sp, args = geometry.KDTreeSearchParamKNN(30), (oracle.KNN, 30, 0.0)
-    else:
+    elif mode == "hybrid":
         sp, args = geometry.KDTreeSearchParamHybrid(5 * s, 40), (oracle.HYBRID, 40, 5 * s)
+    else:
+        # every neighbour within the radius (about 50 here, up to several hundred at the duplicates below), used in the
+        # order of the cell walk: the weighted sums differ from the oracle's ascending-distance order by rounding only
+        pts = pts.copy()
+        pts[100:140] = pts[99]        # duplicates: zero distances (skipped by the weighting, counted by the histograms)
+        pts[7] = np.nan
+        nrm = nrm.copy()
+        pc = geometry.PointCloud(pts, normals=nrm)
+        sp, args = geometry.KDTreeSearchParamRadius(4 * s), (oracle.RADIUS, 0, 4 * s)
     got = reg.ComputeFPFHFeature(pc, sp, ctx=ctx)
+    if mode == "radius":
+        fin = np.isfinite(pts).all(axis=1)
+        ref = np.zeros((len(pts), 33))
+        ref[fin] = oracle.fpfh(pts[fin], nrm[fin], *args)
+        assert not got.data_.T[7].any()
+        g = got.data_.T
+        bad = np.abs(g - ref).max(1) > 1e-9 * 100.0
+        assert bad.sum() <= max(3, len(pts) // 2000), "too many points differ: %d" % bad.sum()
+        return
     ref = oracle.fpfh(pts, nrm, *args)
     assert got.Dimension() == 33 and got.Num() == len(pts)
     g = got.data_.T
@@ -277,8 +295,8 @@ def test_fpfh_edge_cases(ctx):
     nrm = np.tile([0.0, 0.0, 1.0], (500, 1))
     pc = geometry.PointCloud(sc["target"], normals=nrm)
     assert not reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamHybrid(1e-9, 30), ctx=ctx).data_.any()   # nobody has a neighbour
-    with pytest.raises(_lib.O3DError):
-        reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamRadius(0.1), ctx=ctx)   # radius search: not on the device path
+    assert not reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamRadius(1e-9), ctx=ctx).data_.any()
+    assert not reg.ComputeFPFHFeature(pc, geometry.KDTreeSearchParamRadius(0.0), ctx=ctx).data_.any()
     one = geometry.PointCloud(sc["target"][:1], normals=nrm[:1])
     assert reg.ComputeFPFHFeature(one, ctx=ctx).data_.shape == (33, 1)
 
