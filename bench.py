@@ -227,10 +227,12 @@ def main():
             "data": "synthetic",
             "correspondences_per_sec": corr_per_s,
             "config": {
-                "workload": "config 3 headline: point-to-plane ICP, %d source x %d target points on the synthetic height "
-                            "field (L=%.1f m, spacing %.2f mm), max_correspondence_distance = 2 spacings, "
+                "workload": "config 3 headline%s: %s ICP, %d source x %d target points on the synthetic height "
+                            "field (L=%.1f m, spacing %.2f mm), max_correspondence_distance = %d spacings, "
                             "ICPConvergenceCriteria(0,0,%d), source sharded over %d GPU(s), target grid replicated"
-                            % (n, n, scene["L"], 1e3 * s, total_iters, world),
+                            % ("" if args.estimation == "p2plane" else " size, other estimation",
+                               "point-to-plane" if args.estimation == "p2plane" else "point-to-point", n, n, scene["L"], 1e3 * s,
+                               2 if args.estimation == "p2plane" else 3, total_iters, world),
                 "estimation": args.estimation,
                 "fitness": fitness,
                 "inlier_rmse": res.inlier_rmse_,

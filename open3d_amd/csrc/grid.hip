@@ -225,7 +225,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
 __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__restrict__ xyz, const double *__restrict__ nrm,
                                                               const uint32_t *__restrict__ vals, int64_t n_grid, GridParams gp,
                                                               double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted,
-                                                              float4 *__restrict__ tgt_local, double4 *__restrict__ tn_sorted,
+                                                              float4 *__restrict__ tgt_local, double2 *__restrict__ tn_sorted,
                                                               int64_t n_pad) {
   if (blockIdx.x == 0 && threadIdx.x < 4) tgt_local[n_pad + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the read-ahead padding
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
@@ -252,8 +252,9 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
       nrm_sorted[3 * p + 1] = nrm[3 * (size_t)i + 1];
       nrm_sorted[3 * p + 2] = nrm[3 * (size_t)i + 2];
       if (tn_sorted) {
-        tn_sorted[2 * p] = q;
-        tn_sorted[2 * p + 1] = make_double4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], 0.0);
+        tn_sorted[3 * p] = make_double2(q.x, q.y);
+        tn_sorted[3 * p + 1] = make_double2(q.z, nrm[3 * (size_t)i]);
+        tn_sorted[3 * p + 2] = make_double2(nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2]);
       }
     }
   }
@@ -542,7 +543,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
     if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
     want_tn = dev_nrm && allow_bricks && !getenv("O3D_NO_TN");  // (the ICP set-up; the switch is a tuning aid)
-    if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double4) * 2 * (size_t)n));
+    if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double2) * 3 * (size_t)n));
   }
   const size_t ntiles = o3d_sort_num_tiles(n > 0 ? n : 1);
   const size_t nh = 256 * ntiles;

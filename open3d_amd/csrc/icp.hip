@@ -281,7 +281,7 @@ struct PassArgs {
   const double4 *tgt;
   const float4 *tgt_local;
   const double *nrm;
-  const double4 *tn;     // point and normal side by side (two double4 per sorted target point), or null
+  const double2 *tn;     // point and normal side by side (three double2 per sorted target point: 48 bytes), or null
   const uint32_t *cell_start;
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, or -1 none
@@ -819,10 +819,10 @@ __device__ __forceinline__ void cert_body(const PassArgs &a) {
     double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
     double n0 = 0.0, n1 = 0.0, n2 = 0.0, is = 0.0;
     if (has_prev) {
-      if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one aligned 64-byte record instead of two gathers
-        p = a.tn[2 * (size_t)pprev];
-        const double4 nn = a.tn[2 * (size_t)pprev + 1];
-        n0 = nn.x; n1 = nn.y; n2 = nn.z;
+      if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one 48-byte record instead of two gathers of 32 and 24 bytes
+        const double2 r0 = a.tn[3 * (size_t)pprev], r1 = a.tn[3 * (size_t)pprev + 1], r2 = a.tn[3 * (size_t)pprev + 2];
+        p = make_double4(r0.x, r0.y, r1.x, 0.0);  // (the index in p.w is not needed here: a certified entry is not rewritten)
+        n0 = r1.y; n1 = r2.x; n2 = r2.y;
       } else {
         p = a.tgt[pprev];
         if (EST != O3D_EST_POINT_TO_POINT) {
@@ -1098,9 +1098,9 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
     xs = x; ys = y; zs = z;
     if (use_p) {
       if (TN) {  // (never with point-to-point: no normals)
-        p_p = a.tn[2 * (size_t)bpos];
-        const double4 nn = a.tn[2 * (size_t)bpos + 1];
-        n0_p = nn.x; n1_p = nn.y; n2_p = nn.z;
+        const double2 r0 = a.tn[3 * (size_t)bpos], r1 = a.tn[3 * (size_t)bpos + 1], r2 = a.tn[3 * (size_t)bpos + 2];
+        p_p = make_double4(r0.x, r0.y, r1.x, a.tgt[bpos].w);  // the original index rides in tgt_sorted only
+        n0_p = r1.y; n1_p = r2.x; n2_p = r2.y;
       } else {
         p_p = a.tgt[bpos];
         if (EST != O3D_EST_POINT_TO_POINT) {

@@ -100,8 +100,8 @@ struct o3d_ctx {
   int64_t n_tgt_grid = 0;   // finite points placed in the grid
   double4 *tgt_sorted = nullptr;  // {x, y, z, bits(original index)} in cell order
   double *nrm_sorted = nullptr;   // 3 doubles per sorted target point (nullable)
-  double4 *tn_sorted = nullptr;   // point and normal of a sorted target point side by side: {x, y, z, bits(index)}, {nx, ny, nz, 0} --
-                                  // what the estimate's sums gather per correspondence, in ONE aligned 64-byte record
+  double2 *tn_sorted = nullptr;   // point and normal of a sorted target point side by side: {x, y}, {z, nx}, {ny, nz} -- what the
+                                  // estimate's sums gather per correspondence, in ONE 48-byte record (three 16-byte loads)
   size_t cap_tn = 0;
   int tn_valid = 0;               // tn_sorted belongs to the grid in the context
   float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
