@@ -1174,12 +1174,15 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         int st = O3D_OK;
         lead->stream = lead->own_stream;
         if (gs->used > 0)
-          st = o3d_radix_sort_u32(lead, gs->keys, gs->vals, gs->tkeys, gs->tvals, gs->hist, gs->used, 32, false);  // 4 passes: ends at home
+          st = o3d_radix_sort_u32(lead, gs->keys, gs->vals, gs->tkeys, gs->tvals, gs->hist, gs->used, 32, false);
+        // (no copy home: an even number of passes, four for 32 bits, leaves the result where the keys were written)
+        const bool other = o3d_radix_sort_odd(32);
+        const uint32_t *rk = other ? gs->tkeys : gs->keys, *rv = other ? gs->tvals : gs->vals;
         for (auto &job : gs->jobs) {
           bool alive = false;
           for (int k = 0; k < nl; k++) alive = alive || live[k] == job.owner;
           if (!alive || st != O3D_OK) continue;
-          const int js = job.then(gs->keys + job.off, gs->vals + job.off);
+          const int js = job.then(rk + job.off, rv + job.off);
           if (js != O3D_OK) st = js;
         }
         gs->jobs.clear();
