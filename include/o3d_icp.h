@@ -141,7 +141,7 @@ O3D_API int o3d_registration_colored_icp(o3d_ctx *ctx, const double *src_xyz, co
  * (n_tgt[p] points; tgt_nrm may be NULL for point-to-point), init_colmajor + 16 p (init_colmajor NULL: identity) and
  * writes out_transformation + 16 p, out_fitness[p], out_inlier_rmse[p], out_iterations[p], out_n_corr[p] and, when
  * out_corr and out_corr[p] are non-NULL, n_src[p] correspondences.  The pairs are spread over `n_workers` host threads
- * (0: default 6) on ctx's device; each thread advances a GANG of registrations in lock step -- as many as put about six
+ * (0: default 7) on ctx's device; each thread advances a GANG of registrations in lock step -- as many as put about six
  * million source points into a launch, 32 at most, one for pairs that fill the GPU by themselves -- with one launch per
  * pass kernel for the whole gang, so that small pairs do not pay a launch each, and the set-up of one gang overlaps the
  * loop of another.  The context keeps one worker context (stream, grid and source buffers of a pair) per thread and gang

@@ -486,11 +486,16 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
 
   // three events kept on the context: set-up timing is read lazily by o3d_icp_get_setup_ms (a read here would drain the
   // stream once more per call; the batch workers make thousands of small calls)
+  // (not for the slots of a batch's gangs: nobody reads their timing, and every call into the HIP runtime counts there --
+  // eight worker threads were spending 1 ms of host time per set-up, most of it waiting for each other in the runtime)
+  const bool timed = ctx->gang_slots <= 1;
   hipEvent_t *ev = ctx->setup_ev;
-  for (int k = 0; k < 3; k++)
+  for (int k = 0; k < 3 && timed; k++)
     if (!ev[k]) O3D_HIP(ctx, hipEventCreate(&ev[k]));
-  O3D_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
-  O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream));
+  if (timed) O3D_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  // the statistics counters start at zero (the violation counter is cleared by whoever reads it non-zero)
+  if (timed || ctx->tile_stats)
+    O3D_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream));
 
   const void *d_tgt, *d_nrm, *d_src;
   O3D_TRY(to_device(ctx, tgt_xyz, sizeof(double) * 3 * (size_t)n_tgt, mem, &sg->p[0], &sg->cap[0], &d_tgt));
@@ -513,7 +518,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     ctx->slp = sqrt(1.0 - lambda_geometric);
   }
   O3D_TRY(o3d_build_target_grid(ctx, (const double *)d_tgt, (const double *)d_nrm, n_tgt, max_dist, 1));
-  O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+  if (timed) O3D_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
 
   const int apply_init = is_identity(init) ? 0 : 1;  // Registration.cpp:150-152
   O3D_TRY(to_device(ctx, src_xyz, sizeof(double) * 3 * (size_t)n_src, mem, &sg->p[2], &sg->cap[2], &d_src));
@@ -523,7 +528,7 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->sint_sorted, &ctx->cap_sint, sizeof(double) * (size_t)(n_src > 0 ? n_src : 1)));
     O3D_TRY(o3d_launch_color_gather(ctx, (const double *)d_tcol, (const double *)sg->p[6], (const double *)d_scol));
   }
-  O3D_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  if (timed) O3D_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
 
   // loop state
   ctx->estimation = estimation;
@@ -1083,7 +1088,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
   if (n_pairs < 0 || (n_pairs > 0 && (!src_xyz || !n_src || !tgt_xyz || !n_tgt)))
     return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "bad sizes or null buffers");
   if (n_pairs == 0) return O3D_OK;
-  if (n_workers <= 0) n_workers = 6;  // (config 5: 3380 / 3760 / 3760 pairs/s with 4 / 6 / 8)
+  if (n_workers <= 0) n_workers = 7;  // (config 5: 4450 / 4410 / 4330 pairs/s with 7 / 8 / 10)
   if (n_workers > 16) n_workers = 16;
   if ((int64_t)n_workers > n_pairs) n_workers = (int)n_pairs;
   // Each worker thread advances a gang of registrations in lock step (icp.hip, o3d_launch_pass_gang): one launch per pass
@@ -1120,9 +1125,20 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
       if (out_status) out_status[p] = st;
       if (first_status[(size_t)wi] == O3D_OK) { first_status[(size_t)wi] = st; first_error[(size_t)wi] = o3d_last_error(c); }
     };
+    // O3D_BATCH_TIMING=1: where this thread's wall time went (set-up calls / waiting for them and the common sort / passes
+    // enqueued / finish calls), printed once per thread
+    static const bool timing = getenv("O3D_BATCH_TIMING") != nullptr;
+    double t_phase[4] = {0, 0, 0, 0};
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Report {
+      const double *t; int wi; bool on;
+      ~Report() { if (on) fprintf(stderr, "[batch worker %d] set-up calls %.1f ms, sync + common sort %.1f ms, passes enqueued %.1f ms, finish %.1f ms\n", wi, 1e3 * t[0], 1e3 * t[1], 1e3 * t[2], 1e3 * t[3]); }
+    } report{t_phase, wi, timing};
     for (;;) {
       const int64_t base = next.fetch_add(gang);
       if (base >= n_pairs) break;
+      double t0 = timing ? now() : 0.0;
+      auto lap = [&](int k) { if (timing) { const double t1 = now(); t_phase[k] += t1 - t0; t0 = t1; } };
       const int m = (int)std::min<int64_t>(gang, n_pairs - base);
       o3d_ctx *live[O3D_GANG_MAX];
       int64_t live_pair[O3D_GANG_MAX];
@@ -1153,11 +1169,19 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         if (!ok) gs = nullptr;  // (the slots then sort for themselves)
         if (gs) { gs->used = 0; gs->jobs.clear(); }
       }
-      // Set-ups: every slot on its own stream, so that their chains of small kernels (sorts, table, gathers -- half of a
-      // batch's kernel time when they ran one behind the other) overlap; the passes then run on the first slot's stream.
+      // The set-ups of a gang share the gang's stream: with the sorts gone to the common sort a set-up is four small kernels,
+      // and a stream of its own for every slot (31 per thread) meant 31 places to queue up behind other threads' pass kernels
+      // in the four hardware queues (measured on one box, 7 threads: 4035 pairs/s with a stream per slot, 4410 with one).
+      // O3D_BATCH_SLOT_STREAMS=1 brings the streams per slot back (tuning aid).
+      static const bool one_stream = getenv("O3D_BATCH_SLOT_STREAMS") == nullptr;
+      if (mem == O3D_MEM_DEVICE && m > 1)  // every slot's bounding box is on its way before the first set-up waits for one
+        for (int k = 0; k < m; k++) {
+          slot[k]->stream = one_stream ? lead->own_stream : slot[k]->own_stream;
+          (void)o3d_bounds_enqueue(slot[k], tgt_xyz[base + k], n_tgt[base + k]);
+        }
       for (int k = 0; k < m; k++) {
         const int64_t p = base + k;
-        slot[k]->stream = slot[k]->own_stream;
+        slot[k]->stream = one_stream ? lead->own_stream : slot[k]->own_stream;
         slot[k]->gang_sort = gs;
         const int st = o3d_icp_setup(slot[k], src_xyz[p], n_src[p], tgt_xyz[p], tgt_nrm ? tgt_nrm[p] : nullptr, n_tgt[p], max_dist,
                                      init ? init + 16 * p : kIdentity, estimation, with_scaling, rel_fitness, rel_rmse, max_iter, mem,
@@ -1165,9 +1189,11 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         if (st != O3D_OK) { fail(p, st, slot[k]); continue; }  // the other pairs are independent
         live[nl] = slot[k]; live_pair[nl] = p; nl++;
       }
+      lap(0);
       for (int k = 0; k < m; k++) slot[k]->gang_sort = nullptr;
       // (every slot, the failed ones too: their keys lie in the common buffer and must be at rest when the sort counts them)
-      for (int k = 0; k < m; k++) (void)hipStreamSynchronize(slot[k]->own_stream);
+      if (!one_stream)  // (one stream: the sort is simply next in line)
+        for (int k = 0; k < m; k++) (void)hipStreamSynchronize(slot[k]->own_stream);
       for (int k = 0; k < nl; k++) live[k]->stream = lead->own_stream;
       if (gs && !gs->jobs.empty()) {
         // every key of the gang in one sort (32 bits: job number on top), then what each slot queued behind its sort
@@ -1192,6 +1218,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
           nl = 0;
         }
       }
+      lap(1);
       bool together = nl > 1;
       for (int k = 0; k < nl && together; k++)
         together = o3d_gang_eligible(live[k]) && live[k]->use_cert == live[0]->use_cert && live[k]->tn_valid == live[0]->tn_valid;
@@ -1202,6 +1229,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
           loop_status = o3d_launch_pass_gang(lead, live, nl, pass == 0, pass == 0);
         }
       }
+      lap(2);
       for (int k = 0; k < nl; k++) {
         const int64_t p = live_pair[k];
         int st = loop_status;
@@ -1220,6 +1248,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         if (out_rmse) out_rmse[p] = rmse;
         if (out_iters) out_iters[p] = iters;
       }
+      lap(3);
     }
     for (int k = 0; k < gang; k++) {
       slot[k]->stream = slot[k]->own_stream;

@@ -125,6 +125,8 @@ struct o3d_ctx {
   void *d_gang = nullptr, *pinned_gang = nullptr;
   int gang_grid = 0, gang_cert = 0, gang_tn = 0, gang_stream = 0;
   int gang_slots = 0;  // > 1: this context is one slot of a gang of that many (set-up sizes its share of the grid)
+  const double *bounds_for = nullptr;      // o3d_bounds_enqueue: the cloud whose bounding box is on its way to the pinned page
+  int64_t bounds_n = 0;
   int normals_fast = 1;                    // EstimateNormals: FastEigen3x3 (1, the reference default) or Eigen's iterative solver (0)
   o3d_gang_sort *gang_sort = nullptr;      // where this slot's set-up leaves its sorts (not owned), or null
   o3d_gang_sort *gang_sort_own = nullptr;  // the gang's sorter, owned by the gang's first context
@@ -241,6 +243,7 @@ int o3d_exclusive_scan_u32(o3d_ctx *ctx, uint32_t *data, uint32_t *block_sums, i
 // allow_bricks: a scene whose dense table of cells of side max_dist would exceed the budget gets the bricked table instead
 // of coarser cells (only the ICP search kernels read it; every other caller passes 0).
 int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev_nrm, int64_t n, double max_dist, int allow_bricks = 0);
+int o3d_bounds_enqueue(o3d_ctx *ctx, const double *dev_xyz, int64_t n);
 int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double *init_colmajor, int apply_init);
 // AABB over finite points: out6 (host) = {minx,miny,minz,maxx,maxy,maxz}; *out_finite = number of finite points.
 int o3d_bounds(o3d_ctx *ctx, const double *dev_xyz, int64_t n, double out6[6], int64_t *out_finite);
