@@ -781,6 +781,34 @@ int o3d_icp_poll(o3d_ctx *ctx, int *out_done, int *out_passes) {
   return O3D_OK;
 }
 
+// o3d_icp_finish in two halves, so that a gang (o3d_registration_icp_batch) waits for the GPU once, not once per slot:
+// the copies are enqueued on the context's stream; after that stream has been synchronised the results are in the pinned page.
+static int icp_finish_enqueue(o3d_ctx *ctx, int mem, int32_t *out_corr) {
+  if (out_corr && ctx->n_src > 0) {
+    if (mem == O3D_MEM_DEVICE) {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, out_corr));
+    } else {
+      O3D_TRY(o3d_launch_scatter_corr(ctx, ctx->corr_out));
+      O3D_HIP(ctx, o3d_d2h(ctx, out_corr, ctx->corr_out, sizeof(int32_t) * (size_t)ctx->n_src));
+    }
+  }
+  IcpState *hs = reinterpret_cast<IcpState *>((char *)ctx->pinned + 1024);
+  O3D_HIP(ctx, o3d_d2h(ctx, hs, ctx->state, sizeof(IcpState)));
+  O3D_HIP(ctx, enqueue_violation_read(ctx));
+  return O3D_OK;
+}
+static int icp_finish_complete(o3d_ctx *ctx, double out_T[16], int64_t *out_n_corr, double *out_fitness, double *out_rmse,
+                               int *out_iters) {
+  const IcpState *hs = reinterpret_cast<const IcpState *>((const char *)ctx->pinned + 1024);
+  O3D_TRY(check_bound_violations(ctx));
+  if (out_T) memcpy(out_T, hs->T, sizeof(double) * 16);
+  if (out_n_corr) *out_n_corr = (int64_t)hs->n_corr;
+  if (out_fitness) *out_fitness = hs->fitness;
+  if (out_rmse) *out_rmse = hs->rmse;
+  if (out_iters) *out_iters = hs->iters;
+  return O3D_OK;
+}
+
 int o3d_icp_finish(o3d_ctx *ctx, int mem, double out_T[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
                    double *out_rmse, int *out_iters) {
   if (!ctx) return O3D_ERR_INVALID_ARG;
@@ -1230,6 +1258,15 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         }
       }
       lap(2);
+      // the slots' results: with the gang in lock step every copy is enqueued first (all on the gang's stream), then ONE wait
+      int enq_status[O3D_GANG_MAX];
+      if (together && loop_status == O3D_OK) {
+        for (int k = 0; k < nl; k++) {
+          const int64_t p = live_pair[k];
+          enq_status[k] = icp_finish_enqueue(live[k], mem, (out_corr && out_corr[p]) ? out_corr[p] : nullptr);
+        }
+        if (hipStreamSynchronize(lead->own_stream) != hipSuccess) loop_status = o3d_fail(lead, O3D_ERR_HIP, "hipStreamSynchronize");
+      }
       for (int k = 0; k < nl; k++) {
         const int64_t p = live_pair[k];
         int st = loop_status;
@@ -1238,8 +1275,12 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         double T[16], fit = 0.0, rmse = 0.0;
         int64_t nc = 0;
         int iters = 0;
-        if (st == O3D_OK)
+        if (together) {
+          st = enq_status[k];
+          if (st == O3D_OK) st = icp_finish_complete(live[k], T, &nc, &fit, &rmse, &iters);
+        } else if (st == O3D_OK) {
           st = o3d_icp_finish(live[k], mem, T, (out_corr && out_corr[p]) ? out_corr[p] : nullptr, &nc, &fit, &rmse, &iters);
+        }
         if (st != O3D_OK) { fail(p, st, live[k]); continue; }
         if (out_status) out_status[p] = O3D_OK;
         if (out_T) memcpy(out_T + 16 * p, T, sizeof T);
