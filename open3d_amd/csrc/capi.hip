@@ -1218,7 +1218,10 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         live[nl] = slot[k]; live_pair[nl] = p; nl++;
       }
       lap(0);
-      for (int k = 0; k < m; k++) slot[k]->gang_sort = nullptr;
+      for (int k = 0; k < m; k++) {
+        slot[k]->gang_sort = nullptr;
+        slot[k]->bounds_for = nullptr;  // (a set-up that failed early has not picked its box up)
+      }
       // (every slot, the failed ones too: their keys lie in the common buffer and must be at rest when the sort counts them)
       if (!one_stream)  // (one stream: the sort is simply next in line)
         for (int k = 0; k < m; k++) (void)hipStreamSynchronize(slot[k]->own_stream);
