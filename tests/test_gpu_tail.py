@@ -135,3 +135,32 @@ def test_loop_as_graphs_equals_plain_launches(ctx, oracle, n):
                 ref = oracle.registration_icp(sc["source"], sc["target"], r, None, et, nrm)
                 assert got.iterations_ <= 30 and np.array_equal(
                     reg.RegistrationICP(source, target, r, np.eye(4), est, reg.ICPConvergenceCriteria(), ctx=ctx).corr_, ref.corr)
+
+
+@pytest.mark.gpu
+def test_repeated_registrations_on_one_context_repeat_their_bits(ctx):
+    """What a registration leaves behind in the context (work lists, partial rows, tickets, bounds, and whatever sits in the
+    XCDs' caches) must not reach the next one: the same registration run again and again on one context, with registrations
+    of other lengths in between and passes enqueued beyond the end of the loop, returns the same bits every time.  (An
+    experimental one-launch form of the pass failed exactly this and nothing else.)"""
+    import torch
+    from open3d_amd import synthetic
+    from open3d_amd.pipelines import registration as reg
+    n = 30000
+    sc = synthetic.make_pair(n, n, cfg_id=0, L=6.0)
+    s = sc["spacing"]
+    nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+    seen = {}
+    for k in (1, 2, 3, 4, 3, 3, 2, 4, 1, 3):
+        sess = reg.IcpSession(ctx).setup(sc["source"], sc["target"], nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
+                                         reg.ICPConvergenceCriteria(0.0, 0.0, k))
+        for _ in range(6):  # (more than the loop has: the surplus passes return at once)
+            sess.enqueue_step()
+        torch.cuda.synchronize()
+        lg = np.array(sess.log())
+        assert lg.shape[0] == k + 1
+        if k in seen:
+            assert np.array_equal(lg, seen[k]), "registration with %d iterations changed on repetition" % k
+        seen[k] = lg
+    for k in (2, 3, 4):  # a longer registration begins like a shorter one
+        assert np.array_equal(seen[k][: k, 20:], seen[k - 1][: k, 20:])
