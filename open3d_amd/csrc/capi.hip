@@ -598,9 +598,22 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     diag2 += 0.25 * ext * ext;
   }
   hs->radius = sqrt(diag2);
-  // certificates hold while a query moves less than about half the slack its bound was given (the search's extra reach)
-  hs->cert_skip_above = 0.5 * ctx->cert_gap * ctx->gp.h;
-  hs->seed_skip_above = 0.25 * ctx->gp.h;
+  // k_icp_cert stands aside while the pending update moves the cloud farther than twice the slack the bounds were given (the
+  // search's extra reach): beyond that too few certificates survive to pay for the kernel.  Measured on fresh 30-iteration
+  // registrations at 10 M points with factors 0.5 / 1 / 2 / 4 / 16: point-to-point, which keeps sliding, 17.1 / 16.2 / 16.2 /
+  // 16.3 / 16.3 ms of kernels (at 0.5 the first nine passes searched everything); point-to-plane 9.2-9.3 ms whatever the factor
+  double skip_factor = 2.0;
+  if (const char *e = getenv("O3D_CERT_SKIP")) {  // tuning aid
+    const double v = atof(e);
+    if (v > 0.0) skip_factor = v;
+  }
+  hs->cert_skip_above = skip_factor * ctx->cert_gap * ctx->gp.h;
+  double seed_factor = 0.25;
+  if (const char *e = getenv("O3D_SEED_SKIP")) {  // tuning aid
+    const double v = atof(e);
+    if (v > 0.0) seed_factor = v;
+  }
+  hs->seed_skip_above = seed_factor * ctx->gp.h;
   // (the staging page is rewritten by the next set-up on this context at the earliest, and every path to it --
   // o3d_icp_finish, o3d_icp_poll, o3d_icp_fetch, an error -- has synchronised the stream by then)
   O3D_HIP(ctx, o3d_h2d(ctx, ctx->state, hs, sizeof(IcpState)));

@@ -25,8 +25,12 @@ ctx.check(ctx._lib.o3d_estimate_normals(ctx.handle, d_tgt.data_ptr(), n, _lib.SE
 out = {}
 for stats in (False, True):
     ctx.debug_set(collect_tile_stats=stats)
-    sess = reg.IcpSession(ctx).setup(d_src, d_tgt, d_nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
-                                     reg.ICPConvergenceCriteria(0.0, 0.0, iters))
+    if len(sys.argv) > 3 and sys.argv[3] == "p2p":
+        sess = reg.IcpSession(ctx).setup(d_src, d_tgt, None, 3 * s, np.eye(4), reg.TransformationEstimationPointToPoint(),
+                                         reg.ICPConvergenceCriteria(0.0, 0.0, iters))
+    else:
+        sess = reg.IcpSession(ctx).setup(d_src, d_tgt, d_nrm, 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(),
+                                         reg.ICPConvergenceCriteria(0.0, 0.0, iters))
     sess.profile(True)
     cert = []
     for k in range(iters + 1):
