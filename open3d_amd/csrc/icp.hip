@@ -630,7 +630,10 @@ __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_
 // ... whoever owns it.  An item's result is merged into its owner's (best, second-best) pair with LDS atomics; the
 // streaming top-2 rule -- the larger of (incoming, previous best) goes to `second` -- is independent of the order in
 // which the atomics land.  What is not decisive in fp32 is searched again exactly in fp64 on the spot.
-constexpr int kQCap = 256;            // items per wavefront and round (mean demand is ~260; more rounds when it overflows)
+constexpr int kQCap = 512;            // items per wavefront and round; more rounds when a trip's demand overflows (mean ~260).
+                                      // 512 is what four workgroups per CU leave room for in LDS; against 256 the first
+                                      // pass of a 10 M registration takes 0.87 instead of 1.03 ms, thirteen point-to-point
+                                      // passes 7.64 instead of 7.95 ms (A/B on one box); 128 is slower still
 constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
 // an item carries 22 bits of four-candidate chunk index: longer runs go to the exact wave search
 constexpr uint32_t kRunMaxLen = 1u << 24;
