@@ -554,13 +554,17 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     const long v = atol(e);
     if (v >= 8 && v <= O3D_MAX_GRID) gs = (v + 7) / 8 * 8;
   }
-  ctx->search_grid = (int)gs;
+
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
   // Certificates cost a launch and a pass over the source of their own: they pay from a few hundred thousand points on
   // (steady-state iteration at 200 k points 26 us without, 31 us with; at 1 M 61 us without, 51 us with).
   // In a gang (o3d_registration_icp_batch) they always pay: their launch is shared by the whole gang and throughput counts,
   // not the latency of one registration (4096 pairs of 200 k points: 2000 pairs/s without, 3100 with).
   ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : ((n_src >= 400000 || ctx->gang_slots > 1) ? 1 : 0));  // tuning aids
+  // with certificates the pass is one launch (k_icp_pass) when its grid is a multiple of 32 workgroups (icp.hip): rounded up
+  // (the surplus workgroups own empty segments), or down for a gang's share of the resident round
+  if (ctx->use_cert && gs % 32 != 0) gs = (ctx->gang_slots > 1 && gs > 32) ? gs / 32 * 32 : (gs + 31) / 32 * 32;
+  ctx->search_grid = (int)gs;
   ctx->use_tail = getenv("O3D_NO_TAIL") ? 0 : 1;  // tuning aid
   // measured: no gain on ROCm 7.2 (a graph launch of eight kernel nodes costs the host what eight launches cost, and the
   // batch of config 5 runs at the same 2230 pairs/s either way), so the plain launches stay the default

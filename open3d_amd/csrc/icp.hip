@@ -786,17 +786,19 @@ __device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, 
   return r;
 }
 
+constexpr size_t kCertLdsBytes = sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE);
+static_assert(kCertLdsBytes >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
 template <int EST, bool STREAM>
-__device__ __forceinline__ void cert_body(const PassArgs &a) {
+__device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_raw /* kCertLdsBytes, 16-byte aligned */) {
   if (a.st->done) return;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
-  static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned gdim = (unsigned)a.grid_x;
   if (blockIdx.x >= gdim) return;
   const WaveRange wr = wave_range(a.n_src, a.seg_len, gdim);
   if (a.st->skip_cert) {  // the pending update moves the cloud farther than any bound reaches: everything is searched
-    if (tid < O3D_NSUMS) a.partials[((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid] = 0.0;
+    // (a device-scope store like every other partial row: in the one-launch form of the pass the row is read by pass_tail
+    // in the same kernel, possibly from another XCD, which would find last registration's row behind a plain store)
+    if (tid < O3D_NSUMS) store_device_coherent(a.partials + ((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid, 0.0);
     return;
   }
   VBuf &vb = reinterpret_cast<VBuf *>(lds_raw)[tid >> 6];
@@ -905,24 +907,29 @@ struct PassLaunch {
 
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
-  cert_body<EST, false>(a);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
+  cert_body<EST, false>(a, lds_raw);
 }
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_s(PassArgs a) {  // PassArgs::stream
-  cert_body<EST, true>(a);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
+  cert_body<EST, true>(a, lds_raw);
 }
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_ind(const PassLaunch *__restrict__ pl) {
-  cert_body<EST, false>(pl->a);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
+  cert_body<EST, false>(pl->a, lds_raw);
 }
 // ... and for several registrations in lock step (o3d_registration_icp_batch): blockIdx.y names the registration
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch(const PassLaunch *__restrict__ pl) {
-  cert_body<EST, false>(pl[blockIdx.y].a);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
+  cert_body<EST, false>(pl[blockIdx.y].a, lds_raw);
 }
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch_s(const PassLaunch *__restrict__ pl) {
-  cert_body<EST, true>(pl[blockIdx.y].a);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
+  cert_body<EST, true>(pl[blockIdx.y].a, lds_raw);
 }
 
 // The cooperative search (see above CoopWave).  PassArgs::listed: the queries are the work list k_icp_cert left behind
@@ -930,11 +937,10 @@ __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch_s(const PassLau
 // Requires gp.margin (empty outer cell layers): a query with all 26 neighbour cells in the table needs no bounds checks,
 // any other query is at least a cell size away from every target point and has no correspondence.
 template <int EST, bool TN>
-__device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridParams &gp) {
+__device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridParams &gp, CoopWave *wls /* one per wavefront */) {
   const unsigned gdim = (unsigned)a.grid_x;
   if (blockIdx.x >= gdim || a.st->done) return;
-  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
-  static_assert(sizeof(wls) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
+  static_assert(sizeof(CoopWave) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   CoopWave &wl = wls[tid >> 6];
   const double cx0 = uniform_f64(a.st->centre[0]), cy0 = uniform_f64(a.st->centre[1]), cz0 = uniform_f64(a.st->centre[2]);
@@ -1171,15 +1177,46 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
 
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
-  search_coop_body<EST, TN>(a, gp);
+  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  search_coop_body<EST, TN>(a, gp, wls);
 }
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_ind(const PassLaunch *__restrict__ pl) {
-  search_coop_body<EST, TN>(pl->a, pl->gp);
+  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  search_coop_body<EST, TN>(pl->a, pl->gp, wls);
 }
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_batch(const PassLaunch *__restrict__ pl) {
-  search_coop_body<EST, TN>(pl[blockIdx.y].a, pl[blockIdx.y].gp);
+  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  search_coop_body<EST, TN>(pl[blockIdx.y].a, pl[blockIdx.y].gp, wls);
+}
+static_assert(sizeof(CoopWave) * (O3D_BLOCK / O3D_WAVE) >= kCertLdsBytes, "the certificate half stages its vectors in the search's LDS");
+// A pass with certificates as ONE launch: every wavefront certifies its segment (cert_body) and goes straight on to search
+// what it could not certify (search_coop_body over its own work list) -- the two kernels walk the same segments on the same
+// grid, so nothing of the second half waits for another workgroup's first half; the partial rows, their order and the end
+// of the pass (pass_tail) are those of the two launches, and so is every bit of the result
+// (test_one_launch_pass_equals_two_launches).  What it saves is the second launch with its prologue.  Both halves share the
+// workgroup's LDS (the search's queues are the larger).  Two things the two-launch form got for free from the kernel
+// boundary: a workgroup's certificate row must be complete -- and visible device-wide -- when pass_tail adds its group's
+// rows, so the certificate rows start at a multiple of 32 (plan_pass: a row's group is row & 31, and a group is added when
+// its own last workgroup has arrived) and EVERY store to a partial row is a device-scope store, the zero row of a
+// certificate half that stands aside included (as a plain store it sat in its XCD's L2 while another XCD's pass_tail read
+// the previous registration's row from memory: wrong by one registration's sums from the third registration on a context on).
+template <int EST, bool TN>
+__device__ __forceinline__ void pass_body(const PassArgs &a, const GridParams &gp, CoopWave *wls) {
+  cert_body<EST, true>(a, reinterpret_cast<unsigned char *>(wls));
+  __syncthreads();  // (every return of cert_body is taken by the whole workgroup)
+  search_coop_body<EST, TN>(a, gp, wls);
+}
+template <int EST, bool TN>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_pass(PassArgs a, GridParams gp) {
+  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  pass_body<EST, TN>(a, gp, wls);
+}
+template <int EST, bool TN>
+__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_pass_batch(const PassLaunch *__restrict__ pl) {
+  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
+  pass_body<EST, TN>(pl[blockIdx.y].a, pl[blockIdx.y].gp, wls);
 }
 
 // Fixed-order reduction of the workgroup partials (run-to-run deterministic).  1024 threads: thread (g, k) sums
@@ -1698,8 +1735,8 @@ __device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsign
       } else {
         // a grid of fewer than 32 workgroups: group r has no member; its rows -- at most r and r + 32, both rows of
         // k_icp_cert, complete before this kernel began -- are added here, again as finalize_sums would
-        const double x0 = r < a.nparts ? a.partials[(size_t)r * O3D_NSUMS + k] : 0.0;
-        const double x1 = r + 32 < a.nparts ? a.partials[(size_t)(r + 32) * O3D_NSUMS + k] : 0.0;
+        const double x0 = r < a.nparts ? load_device_coherent(a.partials + (size_t)r * O3D_NSUMS + k) : 0.0;
+        const double x1 = r + 32 < a.nparts ? load_device_coherent(a.partials + (size_t)(r + 32) * O3D_NSUMS + k) : 0.0;
         v[r] = 0.0 + (x0 + x1);
       }
     }
@@ -2120,6 +2157,7 @@ struct PassPlan {
   int grows;    // workgroups of the pass kernels
   bool fused;   // k_icp_search_coop (else k_icp_search + k_icp_accumulate_mfma)
   bool tail;    // the search kernel ends the pass itself
+  bool one_launch;  // k_icp_pass: certificates and search of a listed pass in one launch
   int nparts;
 };
 
@@ -2162,6 +2200,11 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pl.nparts = pa.listed ? 2 * pl.grows : pl.grows;
   // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
   pl.tail = pl.fused && ctx->use_tail;
+  {
+    static const char *e = getenv("O3D_ONE_LAUNCH");  // tuning aid: 0 = k_icp_cert and k_icp_search_coop as two launches
+    // (see k_icp_pass for the two conditions on the rows)
+    pl.one_launch = pl.fused && pl.tail && pa.listed && pa.stream && pa.cert_row0 % 32 == 0 && !(e && atoi(e) == 0);
+  }
   pa.tail = pl.tail ? (fuse_solve ? 2 : 1) : 0;
   pa.nparts = pl.nparts; pa.has_normals = ctx->has_tgt_normals; pa.log_rows = ctx->log_rows; pa.log = ctx->log;
   pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
@@ -2188,9 +2231,22 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
     else                                                                                                                   \
       hipLaunchKernelGGL(KERNEL<O3D_EST_POINT_TO_POINT>, dim3(GRID), dim3(O3D_BLOCK), 0, ctx->stream, __VA_ARGS__);        \
   } while (0)
-  if (pa.listed && pa.stream) O3D_LAUNCH_EST(k_icp_cert_s, grows, pa);
+  if (pl.one_launch) {  // k_icp_pass: both halves of the pass in one launch (the profile's first interval stays empty)
+    if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
+    if (pa.tn && est == O3D_EST_POINT_TO_PLANE)
+      hipLaunchKernelGGL((k_icp_pass<O3D_EST_POINT_TO_PLANE, true>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (pa.tn && est == O3D_EST_COLORED_ICP)
+      hipLaunchKernelGGL((k_icp_pass<O3D_EST_COLORED_ICP, true>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (est == O3D_EST_POINT_TO_PLANE)
+      hipLaunchKernelGGL((k_icp_pass<O3D_EST_POINT_TO_PLANE, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else if (est == O3D_EST_COLORED_ICP)
+      hipLaunchKernelGGL((k_icp_pass<O3D_EST_COLORED_ICP, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+    else
+      hipLaunchKernelGGL((k_icp_pass<O3D_EST_POINT_TO_POINT, false>), dim3(grows), dim3(O3D_BLOCK), 0, ctx->stream, pa, ctx->gp);
+  } else if (pa.listed && pa.stream) O3D_LAUNCH_EST(k_icp_cert_s, grows, pa);
   else if (pa.listed) O3D_LAUNCH_EST(k_icp_cert, grows, pa);
-  if (pl.fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
+  if (pl.one_launch) {
+  } else if (pl.fused) {  // profile: [0] = k_icp_cert (nothing in the first pass), [1] = k_icp_search_coop
     if (prof) O3D_HIP(ctx, hipEventRecord(ctx->prof_ev[3 * ctx->prof_n + 1], ctx->stream));
     // (two instantiations rather than a run-time branch: with both gathers compiled in, the kernel spilled six registers)
     if (pa.tn && est == O3D_EST_POINT_TO_PLANE)
@@ -2348,7 +2404,8 @@ int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool uploa
       h[k].a = p0.pa; h[k].gp = c->gp;
       h[O3D_GANG_MAX + k].a = p1.pa; h[O3D_GANG_MAX + k].gp = c->gp;
       const bool ck = p1.pa.listed != 0, tk = p0.pa.tn != nullptr && est != O3D_EST_POINT_TO_POINT;
-      if (k > 0 && (ck != cert || tk != tn || c->estimation != est))
+      if (k == 0) lead->gang_one_launch = p1.one_launch ? 1 : 0;
+      if (k > 0 && (ck != cert || tk != tn || c->estimation != est || (p1.one_launch ? 1 : 0) != lead->gang_one_launch))
         return o3d_fail(lead, O3D_ERR_STATE, "gang: the slots do not run the same kernels");
       cert = ck; tn = tk;
       gx = p0.grows > gx ? p0.grows : gx;
@@ -2359,6 +2416,15 @@ int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool uploa
   const PassLaunch *d = reinterpret_cast<const PassLaunch *>(lead->d_gang) + (first ? 0 : O3D_GANG_MAX);
   const dim3 grid((unsigned)lead->gang_grid, (unsigned)n), block(O3D_BLOCK);
   hipStream_t st = lead->stream;
+  if (!first && lead->gang_cert && lead->gang_one_launch) {
+    if (est == O3D_EST_POINT_TO_PLANE && lead->gang_tn) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_PLANE, true>), grid, block, 0, st, d);
+    else if (est == O3D_EST_POINT_TO_PLANE) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_PLANE, false>), grid, block, 0, st, d);
+    else if (est == O3D_EST_COLORED_ICP && lead->gang_tn) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_COLORED_ICP, true>), grid, block, 0, st, d);
+    else if (est == O3D_EST_COLORED_ICP) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_COLORED_ICP, false>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_POINT, false>), grid, block, 0, st, d);
+    O3D_HIP(lead, hipGetLastError());
+    return O3D_OK;
+  }
   if (!first && lead->gang_cert) {
     if (lead->gang_stream) {
       if (est == O3D_EST_POINT_TO_PLANE) hipLaunchKernelGGL(k_icp_cert_batch_s<O3D_EST_POINT_TO_PLANE>, grid, block, 0, st, d);

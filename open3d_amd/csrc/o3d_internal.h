@@ -123,7 +123,7 @@ struct o3d_ctx {
   long long graph_key = -1;     // kernels and grid the graphs were built for
   // several registrations in lock step (icp.hip, o3d_launch_pass_gang): the lead context's argument table
   void *d_gang = nullptr, *pinned_gang = nullptr;
-  int gang_grid = 0, gang_cert = 0, gang_tn = 0, gang_stream = 0;
+  int gang_grid = 0, gang_cert = 0, gang_tn = 0, gang_stream = 0, gang_one_launch = 0;
   int gang_slots = 0;  // > 1: this context is one slot of a gang of that many (set-up sizes its share of the grid)
   const double *bounds_for = nullptr;      // o3d_bounds_enqueue: the cloud whose bounding box is on its way to the pinned page
   int64_t bounds_n = 0;

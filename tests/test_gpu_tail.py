@@ -164,3 +164,49 @@ def test_repeated_registrations_on_one_context_repeat_their_bits(ctx):
         seen[k] = lg
     for k in (2, 3, 4):  # a longer registration begins like a shorter one
         assert np.array_equal(seen[k][: k, 20:], seen[k - 1][: k, 20:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("est_name,n", [("p2plane", 30000), ("p2p", 30000), ("p2plane", 450000)])
+def test_one_launch_pass_equals_two_launches(est_name, n):
+    """k_icp_pass (certificates and search of a pass in one launch) against k_icp_cert + k_icp_search_coop
+    (O3D_ONE_LAUNCH=0): the same partial rows in the same order, so every logged sum and the transformation must agree bit
+    for bit -- on a fresh context and on later registrations on the same one, whose first listed pass has a certificate
+    half that stands aside and must still overwrite the previous registration's rows for every XCD to see.  The switch is
+    read once per process: the two forms run in two child processes."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from open3d_amd import _lib, synthetic
+from open3d_amd.pipelines import registration as reg
+ctx = _lib.Context(0)
+n = %d
+sc = synthetic.make_pair(n, n, cfg_id=0, L=6.0 if n < 100000 else 20.0)
+s = sc["spacing"]
+plane = %r == "p2plane"
+nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1]) if plane else None
+est = reg.TransformationEstimationPointToPlane() if plane else reg.TransformationEstimationPointToPoint()
+out = []
+for k in (1, 2, 5, 3, 5):
+    sess = reg.IcpSession(ctx).setup(sc["source"], sc["target"], nrm, (2 if plane else 3) * s, np.eye(4), est,
+                                     reg.ICPConvergenceCriteria(0.0, 0.0, k))
+    for _ in range(7):
+        sess.enqueue_step()
+    torch.cuda.synchronize()
+    out.append(np.array(sess.log()).ravel())
+    res = sess.finish()
+    out.append(np.asarray(res.corr_, dtype=np.float64))
+np.save(sys.argv[1], np.concatenate(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, est_name)
+    got = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("1", "0"):
+            env = dict(os.environ, O3D_ONE_LAUNCH=mode, O3D_CERT="1")
+            path = os.path.join(tmp, "r%s.npy" % mode)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=90)
+            got.append(np.load(path))
+    assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
