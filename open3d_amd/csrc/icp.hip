@@ -759,7 +759,7 @@ __device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tg
 // relative slack of 1e-6 -- nine orders of magnitude above the rounding of the fp64 distances they stand for -- so equal
 // distances (ties) can never be certified.
 //
-// A pass with certificates is two launches:
+// A pass with certificates is two halves -- one launch, k_icp_pass (below), or two:
 //   k_icp_cert          streams the source: update in place, certificate, sums of the certified matches on the matrix
 //                       cores; the queries it cannot certify go to a work list (one segment per wavefront, in order, so
 //                       that every sum is added in the same order run after run)
