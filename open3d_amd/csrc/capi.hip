@@ -556,11 +556,11 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   }
 
   ctx->use_seed = getenv("O3D_NO_SEED") ? 0 : 1;  // tuning aid
-  // Certificates cost a launch and a pass over the source of their own: they pay from a few hundred thousand points on
-  // (steady-state iteration at 200 k points 26 us without, 31 us with; at 1 M 61 us without, 51 us with).
-  // In a gang (o3d_registration_icp_batch) they always pay: their launch is shared by the whole gang and throughput counts,
-  // not the latency of one registration (4096 pairs of 200 k points: 2000 pairs/s without, 3100 with).
-  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : ((n_src >= 400000 || ctx->gang_slots > 1) ? 1 : 0));  // tuning aids
+  // Certificates cost a pass over the source of their own: with the pass as one launch (k_icp_pass) they cost a small
+  // cloud nothing (steady-state iteration, without / with: 100 k points 22.8 / 22.6 us, 200 k 27.6 / 27.0) and pay from there
+  // on (300 k: 40.0 / 31.0 us; as a launch of their own they only paid from 400 k points on).  In a gang
+  // (o3d_registration_icp_batch) they always pay (4096 pairs of 200 k points: 2000 pairs/s without, 3100 with, at the time).
+  ctx->use_cert = getenv("O3D_NO_CERT") ? 0 : (getenv("O3D_CERT") ? 1 : ((n_src >= 200000 || ctx->gang_slots > 1) ? 1 : 0));  // tuning aids
   // with certificates the pass is one launch (k_icp_pass) when its grid is a multiple of 32 workgroups (icp.hip): rounded up
   // (the surplus workgroups own empty segments), or down for a gang's share of the resident round
   if (ctx->use_cert && gs % 32 != 0) gs = (ctx->gang_slots > 1 && gs > 32) ? gs / 32 * 32 : (gs + 31) / 32 * 32;

@@ -83,11 +83,11 @@ def test_pass_tail_in_the_stepwise_sharded_form(ctx):
 
 
 def test_certificate_size_policy(ctx):
-    """Without O3D_CERT / O3D_NO_CERT certificates are used from 400 k source points on, and the result does not depend on
+    """Without O3D_CERT / O3D_NO_CERT certificates are used from 200 k source points on, and the result does not depend on
     it: below, the counters show none; above, most of the later passes' queries."""
     from open3d_amd.pipelines import registration as reg
     from open3d_amd import synthetic
-    for n, expect in ((150_000, False), (450_000, True)):
+    for n, expect in ((150_000, False), (250_000, True)):
         sc = make_scene(n, n, cfg_id=5, theta_deg=0.2)
         s = sc["spacing"]
         nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
