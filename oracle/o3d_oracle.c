@@ -1230,6 +1230,53 @@ static int vkey_cmp(const void *a, const void *b) {
   if (A->v[0] != B->v[0]) return A->v[0] < B->v[0] ? -1 : 1;
   return A->i < B->i ? -1 : (A->i > B->i ? 1 : 0);
 }
+/* The same order as qsort(vkey_cmp) -- (z, y, x, input index) ascending -- by a stable LSD radix sort of the packed voxel
+ * index, for the full-size parity tests (100 M points: minutes with qsort, seconds here).  Only an ordering device: the
+ * keys and the sums that follow are untouched.  Returns 0 (nothing done) when the packed index would not fit 64 bits or
+ * any index is negative (NaN / out-of-range input), and the caller falls back to qsort.  orc_voxel_force_qsort lets the
+ * tests compare the two orders. */
+static int g_voxel_force_qsort = 0;
+ORC_EXPORT void orc_voxel_force_qsort(int on) { g_voxel_force_qsort = on; }
+static int orc_voxel_order_radix(vkey *k, int64_t n) {
+  if (g_voxel_force_qsort || n < 2) return 0;
+  int32_t mx[3] = {0, 0, 0};
+  for (int64_t i = 0; i < n; i++)
+    for (int d = 0; d < 3; d++) {
+      if (k[i].v[d] < 0) return 0;
+      if (k[i].v[d] > mx[d]) mx[d] = k[i].v[d];
+    }
+  int bits[3];
+  for (int d = 0; d < 3; d++) {
+    bits[d] = 1;
+    while (bits[d] < 31 && ((int64_t)1 << bits[d]) <= (int64_t)mx[d]) bits[d]++;
+  }
+  const int total = bits[0] + bits[1] + bits[2];
+  if (total > 64) return 0;
+  typedef struct { uint64_t key; int64_t i; } rk;
+  rk *a = (rk *)malloc(sizeof(rk) * (size_t)n), *b = (rk *)malloc(sizeof(rk) * (size_t)n);
+  if (!a || !b) { free(a); free(b); return 0; }
+  for (int64_t i = 0; i < n; i++) {
+    a[i].key = ((uint64_t)k[i].v[2] << (bits[0] + bits[1])) | ((uint64_t)k[i].v[1] << bits[0]) | (uint64_t)k[i].v[0];
+    a[i].i = i;  /* input order: the sort is stable, so equal keys keep ascending i */
+  }
+  for (int shift = 0; shift < total; shift += 11) {
+    size_t cnt[2049];
+    memset(cnt, 0, sizeof cnt);
+    for (int64_t i = 0; i < n; i++) cnt[((a[i].key >> shift) & 2047u) + 1]++;
+    for (int q = 0; q < 2048; q++) cnt[q + 1] += cnt[q];
+    for (int64_t i = 0; i < n; i++) b[cnt[(a[i].key >> shift) & 2047u]++] = a[i];
+    rk *t = a; a = b; b = t;
+  }
+  const uint64_t m0 = ((uint64_t)1 << bits[0]) - 1, m1 = ((uint64_t)1 << bits[1]) - 1;
+  for (int64_t i = 0; i < n; i++) {
+    k[i].v[0] = (int32_t)(a[i].key & m0);
+    k[i].v[1] = (int32_t)((a[i].key >> bits[0]) & m1);
+    k[i].v[2] = (int32_t)(a[i].key >> (bits[0] + bits[1]));
+    k[i].i = a[i].i;
+  }
+  free(a); free(b);
+  return 1;
+}
 ORC_EXPORT int64_t orc_voxel_down_sample(const double *pts, const double *nrm, const double *col, int64_t n, double voxel,
                                          double *out_pts, double *out_nrm, double *out_col, int32_t *out_vox) {
   if (voxel <= 0.0) return -1;
@@ -1244,34 +1291,44 @@ ORC_EXPORT int64_t orc_voxel_down_sample(const double *pts, const double *nrm, c
   if (voxel * (double)INT32_MAX < ext) return -2;
   if (n == 0) return 0;
   vkey *k = (vkey *)malloc(sizeof(vkey) * (size_t)n);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int64_t i = 0; i < n; i++) {
     for (int d = 0; d < 3; d++) k[i].v[d] = (int32_t)floor((pts[3 * i + d] - vmin[d]) / voxel);
     k[i].i = i;
   }
-  qsort(k, (size_t)n, sizeof(vkey), vkey_cmp);
-  int64_t m = 0, a = 0;
-  while (a < n) {
-    int64_t b = a;
+  if (!orc_voxel_order_radix(k, n)) qsort(k, (size_t)n, sizeof(vkey), vkey_cmp);
+  /* voxel boundaries in the sorted order, then one voxel at a time (each voxel's sums run in input order whatever thread
+   * takes it, so the result does not depend on the number of threads) */
+  int64_t *start = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+  int64_t m = 0;
+  for (int64_t a = 0; a < n; a++)
+    if (a == 0 || k[a].v[0] != k[a - 1].v[0] || k[a].v[1] != k[a - 1].v[1] || k[a].v[2] != k[a - 1].v[2]) start[m++] = a;
+  start[m] = n;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int64_t q = 0; q < m; q++) {
+    const int64_t a = start[q], e = start[q + 1];
     double sp[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
-    while (b < n && k[b].v[0] == k[a].v[0] && k[b].v[1] == k[a].v[1] && k[b].v[2] == k[a].v[2]) {
+    for (int64_t b = a; b < e; b++) {
       int64_t i = k[b].i;
       for (int d = 0; d < 3; d++) sp[d] += pts[3 * i + d];
       if (nrm && !isnan(nrm[3 * i]) && !isnan(nrm[3 * i + 1]) && !isnan(nrm[3 * i + 2]))
         for (int d = 0; d < 3; d++) sn[d] += nrm[3 * i + d];
       if (col)
         for (int d = 0; d < 3; d++) sc[d] += col[3 * i + d];
-      b++;
     }
-    double cnt = (double)(b - a);
+    double cnt = (double)(e - a);
     for (int d = 0; d < 3; d++) {
-      out_pts[3 * m + d] = sp[d] / cnt;
-      if (nrm) out_nrm[3 * m + d] = sn[d] / cnt;
-      if (col) out_col[3 * m + d] = sc[d] / cnt;
-      if (out_vox) out_vox[3 * m + d] = k[a].v[d];
+      out_pts[3 * q + d] = sp[d] / cnt;
+      if (nrm) out_nrm[3 * q + d] = sn[d] / cnt;
+      if (col) out_col[3 * q + d] = sc[d] / cnt;
+      if (out_vox) out_vox[3 * q + d] = k[a].v[d];
     }
-    m++;
-    a = b;
   }
+  free(start);
   free(k);
   return m;
 }

@@ -451,3 +451,34 @@ def test_self_adjoint_eigen_solver_restatement(oracle):
     pts = np.concatenate([rng.random((40, 2)), np.zeros((40, 1))], axis=1)
     n_eig = oracle.estimate_normals(pts, oracle.KNN, 10, 0.0, fast=False)
     assert np.allclose(np.abs(n_eig[:, 2]), 1.0, atol=1e-12)
+
+
+def test_voxel_radix_order_equals_qsort_order(oracle):
+    """The oracle orders its voxels with a stable radix sort of the packed voxel index where that fits 64 bits (the full-size
+    GPU tests run it on 100 M points); the order, the sums and the outputs must be those of its qsort path -- also with NaN
+    normals, and with a lattice too fine for 64 bits or a NaN point, where it falls back to qsort by itself."""
+    rng = np.random.default_rng(11)
+    pts = rng.random((200_000, 3)) * np.array([5.0, 3.0, 1.0]) - 2.0
+    nrm = rng.standard_normal(pts.shape)
+    nrm[::97] = np.nan
+    col = rng.random(pts.shape)
+    L = oracle.lib()
+    try:
+        for v in (0.3, 0.05, 0.004, 0.0007, 3e-9):
+            L.orc_voxel_force_qsort(0)
+            a = oracle.voxel_down_sample(pts, v, nrm, col)
+            L.orc_voxel_force_qsort(1)
+            b = oracle.voxel_down_sample(pts, v, nrm, col)
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)), v
+            # numpy's own statement of PointCloud.cpp:288-303 for the points: lexsort by (z, y, x), stable
+            vmin = pts.min(0) - 0.5 * v
+            key = np.floor((pts - vmin) / v).astype(np.int64)
+            order = np.lexsort((key[:, 0], key[:, 1], key[:, 2]))
+            ks = key[order]
+            first = np.ones(len(ks), bool)
+            first[1:] = (ks[1:] != ks[:-1]).any(1)
+            assert np.array_equal(a[3], ks[first].astype(np.int32))
+            cnt = np.diff(np.append(np.nonzero(first)[0], len(ks)))
+            assert np.allclose(a[0], np.add.reduceat(pts[order], np.nonzero(first)[0]) / cnt[:, None], rtol=1e-13, atol=1e-13)
+    finally:
+        L.orc_voxel_force_qsort(0)
