@@ -22,16 +22,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(scene, normals, radius, n_sample, iters, est_type=2):
+def cpu_baseline(scene, normals, radius, n_sample, iters, est_type=2, serial=False):
     """Oracle (FLANN-shaped KD-tree restatement, OpenMP) on a bounded sample of the same workload.  Returns the baseline
     record and the oracle's result (per-pass log, final correspondences) for the parity check."""
     import oracle
     oracle.build()
-    threads = oracle.max_threads()
+    threads = 1 if serial else oracle.max_threads()
     src = scene["source"][:n_sample]
     t0 = time.time()
     res = oracle.registration_icp(src, scene["target"], radius, None, est_type, normals, rel_fitness=0.0, rel_rmse=0.0, max_iter=iters,
-                                  want_log=True)
+                                  want_log=True, serial=serial)
     wall = time.time() - t0
     n_full = len(scene["source"])
     loop_s = res.loop_seconds  # first LOOP-A pass .. last, KD-tree build excluded (as for the GPU figure)
@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--estimation", default="p2plane", choices=["p2plane", "p2p"])
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-sample-1t", type=int, default=500_000, help="source points of the one-thread CPU baseline leg")
+    ap.add_argument("--no-hard-scene", dest="hard_scene", action="store_false", help="skip the hard-scene leg (config.hard_scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks", type=int, default=5,
                     help="the timed region is repeated this many times back to back (value = median block), steps iterations each")
@@ -153,59 +155,144 @@ def main():
     icp = ShardedICP(engine, None, dev, force_exchange=args.force_exchange)
     est = reg.TransformationEstimationPointToPlane() if args.estimation == "p2plane" else reg.TransformationEstimationPointToPoint()
     blocks = max(1, args.blocks)
-    total_iters = args.warmup + blocks * args.steps
-    crit = reg.ICPConvergenceCriteria(0.0, 0.0, total_iters)
 
     def barrier():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # An untimed rehearsal of the first iterations of this registration (code objects, caches, clocks), then the real thing.
-    icp.setup(d_src, d_tgt, d_nrm, radius, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, 4), n)
-    for _ in range(5):
-        icp.step()
-    barrier()
-    icp.setup(d_src, d_tgt, d_nrm, radius, np.eye(4), est, crit, n)
-    setup_ms = engine.sess.setup_ms()
-    barrier()
-    engine.sess.profile(True)
-    # pass 0 (the initial correspondence search, Registration.cpp:154) + warmup iterations: not part of `value`, but timed
-    # for the whole-call figure in config (a loop that starts from scratch pays for them)
-    t_first = time.perf_counter()
-    icp.step()
-    for _ in range(args.warmup):
-        icp.step()
-    barrier()
-    head_s = time.perf_counter() - t_first
-    head_ms = engine.sess.profile_read_all()
-    engine.sess.profile_read2()  # clears the record: what follows is the timed region only
-    # the timed region: `blocks` x `steps` iterations, each block bracketed by barrier + synchronize
-    block_s = []
-    for _ in range(blocks):
+    def fresh_registration(src_t, tgt_t, nrm_t, r, k_iters, n_global, timed_profile=True):
+        """One registration from scratch with ICPConvergenceCriteria(0, 0, k_iters): set-up (grid build, source sort: not
+        timed, reported separately), then t_loop = the first correspondence pass (Registration.cpp:154) through
+        the last of the k_iters iterations (:155-166), bracketed by barrier + synchronize.  Returns (t_loop seconds,
+        kernel ms of every pass by HIP events, set-up ms)."""
+        icp.setup(src_t, tgt_t, nrm_t, r, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, k_iters), n_global)
+        sms = engine.sess.setup_ms()
+        barrier()
+        engine.sess.profile(bool(timed_profile))
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        icp.step()                      # pass 0 and the first estimate
+        for _ in range(k_iters):
             icp.step()
         barrier()
-        block_s.append(time.perf_counter() - t0)
+        t = time.perf_counter() - t0
+        ms = engine.sess.profile_read_all() if timed_profile else np.zeros(0)
+        engine.sess.profile(False)
+        return t, ms, sms
+
+    # W untimed warm-up steps (a rehearsal registration: code objects, caches, clocks), then the timed region: `blocks`
+    # registrations from scratch of K iterations each.  value = K / median t_loop  (SURVEY 8d: iters/s = M / t_loop).
+    fresh_registration(d_src, d_tgt, d_nrm, radius, max(args.warmup, 1), n, timed_profile=False)
+    block_s, block_ms, setup_ms = [], [], None
+    for _ in range(blocks):
+        t, ms, setup_ms = fresh_registration(d_src, d_tgt, d_nrm, radius, args.steps, n)
+        block_s.append(t)
+        block_ms.append(ms)
+    res = icp.finish(want_corr=False)
     if dist.is_initialized():
         t = torch.tensor(block_s, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         block_s = [float(v) for v in t.cpu()]
     dt = float(np.median(block_s))
-    pass_ms = engine.sess.profile_read_all()
-    (first_ms, second_ms), kern_n = engine.sess.profile_read2()  # f32 path: k_icp_cert, k_icp_search_coop; f64 path: search, accumulate
-    search_ms = first_ms
-    kern_ms = first_ms + second_ms
-    one_launch = args.search == "f32" and first_ms < 0.02 < second_ms  # k_icp_pass: nothing between the first two events
-    res = icp.finish(want_corr=False)
     n_corr_global = res.n_corr_
     fitness = res.fitness_
+    per_pass = np.median(np.stack(block_ms), axis=0) if len(block_ms[0]) == args.steps + 1 else np.zeros(args.steps + 1)
+    pass0_ms = float(per_pass[0])                 # k_icp_search_coop over everything (nothing to certify yet)
+    kern_ms = float(np.mean(per_pass[1:]))        # k_icp_pass, averaged over the K launches of a block
+    kern_n = blocks * args.steps
+    one_launch = args.search == "f32"
+
+    # The converged regime for comparison with earlier rounds (their `value`): the same registration kept going, K more
+    # iterations timed once its first W + 3 have passed (every match certified, no search).
+    steady = None
+    if True:
+        total = args.warmup + 3 + args.steps
+        icp.setup(d_src, d_tgt, d_nrm, radius, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, total), n)
+        for _ in range(1 + args.warmup + 3):
+            icp.step()
+        barrier()
+        engine.sess.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            icp.step()
+        barrier()
+        st = time.perf_counter() - t0
+        sms_ = engine.sess.profile_read_all()
+        engine.sess.profile(False)
+        if dist.is_initialized():
+            tt = torch.tensor([st], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            st = float(tt.cpu()[0])
+        steady = {"iters_per_s": args.steps / st, "ms_per_step": 1e3 * st / args.steps,
+                  "pass_kernel_ms": float(np.median(sms_)) if len(sms_) else None,
+                  "what": "iterations %d..%d of one registration with ICPConvergenceCriteria(0,0,%d): the source no longer moves, "
+                          "every previous match is certified (rounds 1-2 reported this as `value`)" % (args.warmup + 4, total, total)}
+        icp.finish(want_corr=False)
+
+    # What a caller waits for with the reference's default criteria (1e-6, 1e-6, 30), wall-timed around set-up -> loop ->
+    # results with every buffer resident in HBM (the PCIe-inclusive figure for host buffers is in DESIGN.md).
+    def default_call(src_t, tgt_t, nrm_t, r):
+        corr = torch.empty(src_t.shape[0], dtype=torch.int32, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        icp.setup(src_t, tgt_t, nrm_t, r, np.eye(4), est, reg.ICPConvergenceCriteria(), n)
+        icp.run()
+        r_ = engine.sess.finish(corr_out=corr)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0), r_
+    default_call(d_src, d_tgt, d_nrm, radius)
+    default_ms, default_res = default_call(d_src, d_tgt, d_nrm, radius)
+    fresh30_ms = None
+    if args.steps != 30:
+        t30 = [fresh_registration(d_src, d_tgt, d_nrm, radius, 30, n, timed_profile=False)[0] for _ in range(3)]
+        fresh30_ms = 1e3 * float(np.median(t30))
+    else:
+        fresh30_ms = 1e3 * dt
+
+    # A scene that keeps moving (VERDICT r2): rotation 1 degree, translation 6 spacings, search radius 4 spacings -- most
+    # passes search a large part of the cloud instead of certifying it.  Generated on the device (same generator).
+    hard = None
+    if world == 1 and args.hard_scene and args.estimation == "p2plane":
+        hs = synthetic.make_pair_device(ctx, n, n, cfg_id=33, theta_deg=1.0, tau_in_spacings=(4.0, -3.5, 2.9), want_normals=False)
+        h_nrm = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        ctx.check(ctx._lib.o3d_estimate_normals(ctx.handle, hs["target"].data_ptr(), n, _lib.SEARCH_HYBRID, 30, 4.0 * s, _lib.MEM_DEVICE,
+                                                h_nrm.data_ptr(), 0))
+        hr = 4.0 * s
+        fresh_registration(hs["source"], hs["target"], h_nrm, hr, 30, n, timed_profile=False)
+        ht, hms = [], []
+        for _ in range(3):
+            t, ms, _sm = fresh_registration(hs["source"], hs["target"], h_nrm, hr, 30, n)
+            ht.append(t)
+            hms.append(ms)
+        hres = icp.finish(want_corr=False)
+        hpp = np.median(np.stack(hms), axis=0)
+        # share of the queries certified without a search in every pass (statistics on: an untimed run, polled per pass)
+        ctx.debug_set(use_tile_search=True, collect_tile_stats=True)
+        icp.setup(hs["source"], hs["target"], h_nrm, hr, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, 30), n)
+        ctx.tile_stats(reset=True)
+        cert_frac = []
+        for _ in range(31):
+            icp.step()
+            cert_frac.append(round(ctx.tile_stats(reset=True)["certified"] / n, 4))
+        icp.finish(want_corr=False)
+        ctx.debug_set(use_tile_search=(args.search == "f32"), collect_tile_stats=False)
+        hbytes = n * 52 + hres.fitness_ * n * 48
+        hdt = float(np.median(ht))
+        hdef_ms, hdef = default_call(hs["source"], hs["target"], h_nrm, hr)
+        hard = {"what": "10 M x 10 M point-to-plane, rotation 1 deg about (1,2,3), translation (4,-3.5,2.9) spacings (|t| = 6.1), "
+                        "max_correspondence_distance = 4 spacings, ICPConvergenceCriteria(0,0,30), registration from scratch",
+                "iters_per_s": 30 / hdt, "t_loop_ms": 1e3 * hdt, "fitness": hres.fitness_, "inlier_rmse": hres.inlier_rmse_,
+                "max_abs_T_error_vs_truth": float(np.abs(hres.transformation_ - hs["T_true"]).max()),
+                "kernel_ms_per_pass": [round(float(v), 4) for v in hpp],
+                "certified_fraction_per_pass": cert_frac,
+                "frac_of_hbm_roofline": hbytes * 31 / (float(hpp.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "default_criteria_call_ms": hdef_ms, "default_criteria_iterations": hdef.iterations_}
+        del hs, h_nrm
 
     if rank == 0:
         iters_per_s = args.steps / dt
-        corr_per_s = args.steps * n / dt
-        # algorithmic bytes of one pass (one k_icp_search_coop launch) on this rank: per source point 24 B read + 24 B
+        corr_per_s = (args.steps + 1) * n / dt
+        # algorithmic bytes of one pass (one k_icp_pass launch) on this rank (SURVEY.md 8d): per source point 24 B read + 24 B
         # written (in-place transform) + 4 B correspondence; per correspondence 24 B target point + 24 B normal
         n_shard = hi - lo
         nc_shard = fitness * n_shard
@@ -233,7 +320,12 @@ def main():
                             "ICPConvergenceCriteria(0,0,%d), source sharded over %d GPU(s), target grid replicated"
                             % ("" if args.estimation == "p2plane" else " size, other estimation",
                                "point-to-plane" if args.estimation == "p2plane" else "point-to-point", n, n, scene["L"], 1e3 * s,
-                               2 if args.estimation == "p2plane" else 3, total_iters, world),
+                               2 if args.estimation == "p2plane" else 3, args.steps, world),
+                "timed_region": "value = K / t_loop of a registration FROM SCRATCH (SURVEY 8d): after %d untimed warm-up steps of a "
+                                "rehearsal registration, %d registrations are set up anew (grid build and source sort untimed, "
+                                "reported below) and each is timed from its first correspondence pass (Registration.cpp:154) "
+                                "through the last of its K = %d iterations -- K + 1 passes, the first two of which search the whole "
+                                "cloud; median over the registrations" % (max(args.warmup, 1), blocks, args.steps),
                 "estimation": args.estimation,
                 "fitness": fitness,
                 "inlier_rmse": res.inlier_rmse_,
@@ -244,26 +336,22 @@ def main():
                 "estimate_normals_ms_device_resident": normals_dev_ms,
                 "blocks": blocks,
                 "iters_per_s_min_median_max": [args.steps / max(block_s), iters_per_s, args.steps / min(block_s)],
-                "kernel_ms_per_pass_min_max": [float(pass_ms.min()), float(pass_ms.max())] if len(pass_ms) else None,
-                # a registration that starts from scratch: its first passes search everything (nothing to certify yet)
-                "first_passes_kernel_ms": [round(float(v), 4) for v in head_ms[: 1 + args.warmup]],
-                "first_passes_wall_ms": 1e3 * head_s,
-                "fresh_call_30_iterations_kernel_ms_estimate": float(sum(head_ms[:2]) + 29 * np.median(pass_ms)) if len(head_ms) >= 2 and len(pass_ms) else None,
+                "kernel_ms_per_pass": [round(float(v), 4) for v in per_pass],
+                "fresh_call_0_0_30_ms": fresh30_ms,
+                "fresh_call_0_0_30_iters_per_s": 30.0 / (fresh30_ms * 1e-3) if fresh30_ms else None,
+                "default_criteria_call_ms": default_ms,
+                "default_criteria_call": "ICPConvergenceCriteria(1e-6, 1e-6, 30): %d iterations; wall time of set-up (grid build, source "
+                                         "sort) + loop + results, buffers resident in HBM" % default_res.iterations_,
+                "steady_state": steady,
+                "hard_scene": hard,
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_icp_pass: ONE launch per ICP pass -- every wavefront streams its segment of the source (update in place, "
-                           "certified previous matches, MFMA sums: the k_icp_cert half), searches what it could not certify (the "
-                           "k_icp_search_coop half) and the last workgroups to arrive add the partial rows and solve the 6x6 system.  "
-                           "HIP events on the launch stream"
-                           if one_launch else
-                           "k_icp_cert (update in place + certified previous matches + MFMA sums) and k_icp_search_coop (exact "
-                           "correspondence search of what is left + MFMA sums): the two kernels of an ICP pass (O3D_ONE_LAUNCH=0); "
-                           "the second one also ends the pass (its last workgroups add the partial rows and solve the 6x6 system: no third launch).  HIP events on the launch stream")
+                           "certified previous matches, MFMA sums), searches what it could not certify, and the last workgroups to "
+                           "arrive add the partial rows and solve the 6x6 system.  Average over the K launches of a timed registration "
+                           "(the first of them searches the whole cloud, the rest certify); HIP events on the launch stream")
                           if args.search == "f32" else "k_icp_search + k_icp_accumulate_mfma (all-fp64 path)",
-                # (one launch: the first interval of the pass profile is empty, the second is the whole pass)
-                "cert_kernel_ms" if args.search == "f32" else "search_kernel_ms": None if one_launch else search_ms,
-                ("pass_kernel_ms" if one_launch else "search_kernel_ms") if args.search == "f32" else "second_kernel_ms": second_ms,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -272,11 +360,17 @@ def main():
                 "kernel_ms": kern_ms,
                 "launches_timed": kern_n,
                 "algorithmic_bytes_per_launch": bytes_launch,
+                # the other kernel of the loop: the initial correspondence pass (nothing to certify: searches everything)
+                "search_pass": {"kernel": "k_icp_search_coop (pass 0 of a registration)", "kernel_ms": pass0_ms,
+                                "achieved": bytes_launch / (pass0_ms * 1e-3) / 1e9 if pass0_ms > 0 else None,
+                                "frac": bytes_launch / (pass0_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if pass0_ms > 0 else None},
+                "steady_state_frac": (bytes_launch / (steady["pass_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+                                     if steady and steady.get("pass_kernel_ms") else None,
             },
         }
-        # HBM traffic per pass from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be read from
-        # inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; applied to all reads,
-        # so an upper bound) + WRITE_SIZE, summed over the two kernels of a pass.  Only quoted for the workload it was collected on.
+        # HBM traffic per k_icp_pass launch from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be
+        # read from inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; applied to all
+        # reads, so an upper bound) + WRITE_SIZE.  Only quoted for the workload it was collected on.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and n == 10_000_000 and args.estimation == "p2plane" and args.search == "f32" and os.path.exists(tpath):
             with open(tpath) as f:
@@ -287,6 +381,9 @@ def main():
             n_sample = min(args.cpu_sample, n)
             est_type = 2 if args.estimation == "p2plane" else 1
             out["cpu_baseline"], ref = cpu_baseline(scene, normals, radius, n_sample, args.cpu_iters, est_type)
+            # ... and with one thread (the reference's own CMakeLists.txt builds without OpenMP): a smaller sample, scaled
+            out["cpu_baseline"]["single_thread"] = cpu_baseline(scene, normals, radius, min(args.cpu_sample_1t, n), 1, est_type,
+                                                                serial=True)[0]
             # the oracle run is not thrown away: the GPU must reproduce it (checker only -- nothing of it is timed or shipped)
             out["config"]["parity_%s" % ("%dM" % (n // 1_000_000) if n >= 1_000_000 else str(n))] = parity_check(
                 ctx, reg, d_src, d_tgt, d_nrm, radius, est, args.cpu_iters, n_sample, ref)

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -31,6 +32,11 @@
 /* ------------------------------------------------------------------------- */
 /* Threads                                                                    */
 /* ------------------------------------------------------------------------- */
+static double orc_wall_seconds(void) { /* (the serial build has no omp_get_wtime) */
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 ORC_EXPORT int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -805,9 +811,7 @@ ORC_EXPORT int orc_registration_icp(const double *src, int64_t ns, const double 
   if (!orc_is_identity(init)) orc_transform_points(init, pcd, ns);
   int64_t nc;
   double sd2, fit, rmse;
-#ifdef _OPENMP
-  double t0 = omp_get_wtime();
-#endif
+  double t0 = orc_wall_seconds();
   orc_correspondences(pcd, ns, tgt, nt, kd, max_dist, use_brute, corr_out, &nc, &sd2, &fit, &rmse);
   int pass = 0;
   if (log) { log[0] = fit; log[1] = rmse; log[2] = (double)nc; log[3] = sd2; memcpy(log + 4, T, sizeof T); }
@@ -827,11 +831,7 @@ ORC_EXPORT int orc_registration_icp(const double *src, int64_t ns, const double 
     }
     if (fabs(bf - fit) < rel_fitness && fabs(br - rmse) < rel_rmse) { it++; break; }
   }
-#ifdef _OPENMP
-  if (time_loop_s) *time_loop_s = omp_get_wtime() - t0;
-#else
-  if (time_loop_s) *time_loop_s = 0;
-#endif
+  if (time_loop_s) *time_loop_s = orc_wall_seconds() - t0;
   memcpy(T_out, T, sizeof T);
   *n_corr_out = nc;
   *fitness_out = fit;
