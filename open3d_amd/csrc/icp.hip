@@ -21,6 +21,10 @@
 
 #include "o3d_internal.h"
 
+#ifndef O3D_CENTRE_MIN
+#define O3D_CENTRE_MIN 64
+#endif
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -589,7 +593,8 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
 // second - best > 2e and |best - thr| > e; runs are pruned only when their face distance exceeds best + 4e.
 constexpr float kF32Err = 4e-6f;
 constexpr float kSeedMax = 0.9f;   // a seed farther than sqrt(kSeedMax) cells prunes worse than the centre-cell phase
-constexpr int kMaxRuns = 10;  // left cell, right cell, eight neighbouring rows
+constexpr uint32_t kCentrePhaseMin = O3D_CENTRE_MIN;  // items (of four candidates) per wavefront that make a cooperative round of the own cells worth its set-up
+constexpr int kMaxRuns = 11;  // rest of the own cell, left cell, right cell, eight neighbouring rows
 
 // Four consecutive cell-table entries in one 16-byte load (the table is only 4-byte aligned at an arbitrary cell:
 // gfx950 global loads take dword-aligned dwordx4 addresses).  One L1 access instead of four.
@@ -616,7 +621,7 @@ __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_
     const float dz = qz - c[u].z;
     float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     if (u > 0 && j + u >= e) d2 = INFINITY;
-    st.second = fminf(st.second, fmaxf(d2, st.best));
+    st.second = __builtin_amdgcn_fmed3f(d2, st.best, st.second);  // best <= second always: the median is the new runner-up
     st.bpos = d2 < st.best ? j + u : st.bpos;
     st.best = fminf(st.best, d2);
   }
@@ -634,12 +639,11 @@ constexpr int kQCap = 512;            // items per wavefront and round; more rou
                                       // 512 is what four workgroups per CU leave room for in LDS; against 256 the first
                                       // pass of a 10 M registration takes 0.87 instead of 1.03 ms, thirteen point-to-point
                                       // passes 7.64 instead of 7.95 ms (A/B on one box); 128 is slower still
-constexpr int kCentreSlot = 0;        // run-list slot of the centre cell (phase 2 reuses the slots)
 // an item carries 22 bits of four-candidate chunk index: longer runs go to the exact wave search
 constexpr uint32_t kRunMaxLen = 1u << 24;
 struct CoopWave {
   union {
-    uint2 runs[kMaxRuns][O3D_WAVE];   // [slot][lane]: the lane's run list (phase 1: slot 0 = centre cell)
+    uint2 runs[kMaxRuns][O3D_WAVE];   // [slot][lane]: the lane's run list
     VBuf vb;                          // after the search: staging of the estimate's vectors for the matrix cores
   };
   float4 q[O3D_WAVE];                 // query: position inside its cell, w = bits(padded x cell index)
@@ -653,6 +657,23 @@ __device__ __forceinline__ uint2 make_run(uint32_t s, uint32_t e, int dy, int dz
   return make_uint2(s, ((e - s) << 4) | (uint32_t)((dy + 1) | ((dz + 1) << 2)));
 }
 
+// Inclusive prefix sum over the wavefront's 64 lanes in six DPP additions (row shifts inside the rows of 16 lanes, then the
+// two row broadcasts of gfx9), instead of six ds_bpermute round trips through the LDS crossbar.  Lanes without a source
+// lane -- and rows outside a broadcast's row mask -- take the `old` operand, 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // One phase: every lane brings runs in consecutive slots of its LDS column starting at `first`, `tot` items in all.
 __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, int lane, int first, uint32_t tot, const float4 *__restrict__ tl,
                                                float hf) {
@@ -660,13 +681,8 @@ __device__ __forceinline__ unsigned coop_phase(CoopWave &wl, int lane, int first
   uint32_t ch = 0, nch = 0;
   unsigned trips = 0;
   for (;;) {
-    uint32_t incl = tot;
-#pragma unroll
-    for (int d = 1; d < O3D_WAVE; d <<= 1) {
-      const uint32_t o = __shfl_up(incl, d, O3D_WAVE);
-      if (lane >= d) incl += o;
-    }
-    const uint32_t total = __shfl(incl, O3D_WAVE - 1, O3D_WAVE);
+    const uint32_t incl = wave_inclusive_sum(tot);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, O3D_WAVE - 1);
     if (total == 0) break;
     const uint32_t off = incl - tot;
     uint32_t quota = off >= (uint32_t)kQCap ? 0u : min(tot, (uint32_t)kQCap - off);
@@ -961,7 +977,6 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   const float capsq = cap * cap;
   const float4 *__restrict__ tl = a.tgt_local;
   const uint32_t *__restrict__ cs = a.cell_start;
-  const unsigned long long kBestInit = (unsigned long long)0x7F800000u << 32;  // +inf, position 0
   const int row_y = o3d_row_stride_y(gp), row_z = o3d_row_stride_z(gp);  // table strides of one cell in y / z (wave-uniform)
 
   // The fp32 winner is confirmed in fp64 with the arithmetic of the exact search (it then IS the exact result: every
@@ -1039,14 +1054,29 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
       seedb = (float)(ddx * ddx + ddy * ddy + ddz * ddz) * 1.000001f + err;  // >= the exact distance, in fp32
     }
     const bool seeded = seedb <= seed_max && !too_long;
-    // phase 1: the centre cells of the wavefront's queries that have no usable seed
+    // First bound for a query without a usable seed: the first four candidates of its own cell, scanned by the lane itself --
+    // one address, four loads, no queue (most centre cells hold no more; what they hold beyond goes to the queue below
+    // with the neighbouring cells).  A cooperative phase of its own for the centre cells cost a prefix sum, a queue and two
+    // rounds of LDS atomics per trip for 1.5 dense rounds of work.
+    F32State st0;
+    st0.best = INFINITY; st0.second = INFINITY; st0.bpos = 0;
+    const bool own = inside && !too_long && !seeded && s1 < s2;
+    if (own) scan4_f32(tl, s1, s2, qx, qy, qz, cx + 1, hf, st0);
     wl.q[lane] = make_float4(qx, qy, qz, __int_as_float(cx + 1));
-    wl.best[lane] = kBestInit;
-    wl.second[lane] = 0x7F800000u;
-    wl.runs[kCentreSlot][lane] = make_run(s1, (too_long || seeded) ? s1 : s2, 0, 0);
-    wave_lds_sync();
-    unsigned trips = coop_phase(wl, lane, kCentreSlot, (too_long || seeded) ? 0u : (s2 - s1 + 3u) >> 2, tl, hf);
-    const float best1 = seeded ? seedb : __uint_as_float((uint32_t)(wl.best[lane] >> 32));
+    wl.best[lane] = ((unsigned long long)__float_as_uint(st0.best) << 32) | st0.bpos;
+    wl.second[lane] = __float_as_uint(st0.second);
+    // Dense cells (a search radius of several point spacings): where the wavefront's own cells hold a round of work beyond
+    // their first chunks, those are scanned cooperatively before the listing, so that the bound the neighbouring cells are
+    // pruned with is the whole cell's; otherwise they ride along with the neighbours' runs.
+    const uint32_t rem = (own && s2 - s1 > 4u) ? (s2 - s1 - 1u) >> 2 : 0u;
+    const bool centre_phase = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(rem), O3D_WAVE - 1) >= kCentrePhaseMin;
+    unsigned trips = 0;
+    if (centre_phase) {  // wave-uniform
+      wl.runs[0][lane] = make_run(s1 + 4u, rem ? s2 : s1 + 4u, 0, 0);
+      wave_lds_sync();
+      trips = coop_phase(wl, lane, 0, rem, tl, hf);
+    }
+    const float best1 = seeded ? seedb : (centre_phase ? __uint_as_float((uint32_t)(wl.best[lane] >> 32)) : st0.best);
     // phase 2: the runs that survive the face-distance pruning against the centre result.  The table rows are loaded
     // only now and only where the bound lets them matter (one masked 16-byte load per needed row, all in flight
     // together), instead of eight loads per query up front.
@@ -1077,6 +1107,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
         const uint32_t s = axm <= reach ? s0 : s1, e = axp <= reach ? s3 : s2;
         if (s < e) { wl.runs[nruns][lane] = make_run(s, e, 0, 0); tot += (e - s + 3u) >> 2; nruns++; }
       } else {
+        if (rem && !centre_phase) { wl.runs[nruns][lane] = make_run(s1 + 4u, s2, 0, 0); tot += rem; nruns++; }  // the rest of the own cell
         if (axm <= reach && s0 < s1) { wl.runs[nruns][lane] = make_run(s0, s1, 0, 0); tot += (s1 - s0 + 3u) >> 2; nruns++; }
         if (axp <= reach && s2 < s3) { wl.runs[nruns][lane] = make_run(s2, s3, 0, 0); tot += (s3 - s2 + 3u) >> 2; nruns++; }
       }
@@ -1147,7 +1178,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
     }
     if (a.stats) {
       const unsigned long long np = __popcll(undecided), nv = __popcll(__ballot(valid));
-      unsigned long long rsum = (unsigned long long)nruns, isum = tot + ((s2 - s1 + 3u) >> 2);
+      unsigned long long rsum = (unsigned long long)nruns, isum = tot + (own ? 1u : 0u);
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
         rsum += __shfl_xor(rsum, d, O3D_WAVE);

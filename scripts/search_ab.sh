@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of prebuilt library variants (variants/lib<name>.so) with scripts/search_ab.py; every step under its own time limit
+set -e
+for v in "$@"; do
+  cp variants/lib$v.so open3d_amd/libo3d_amd.so
+  timeout -k 10 120 python3 scripts/search_ab.py $v >> gpurun_out/search_ab.jsonl 2>> gpurun_out/search_ab.err
+  tail -1 gpurun_out/search_ab.jsonl
+done
