@@ -392,7 +392,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_launch,   ctx->d_gang};
+                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_launch,   ctx->d_gang, ctx->tgt_index};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
                                                               const uint32_t *__restrict__ vals, int64_t n_grid, GridParams gp,
                                                               double4 *__restrict__ tgt_sorted, double *__restrict__ nrm_sorted,
                                                               float4 *__restrict__ tgt_local, double2 *__restrict__ tn_sorted,
-                                                              int64_t n_pad) {
+                                                              uint32_t *__restrict__ tgt_index, int64_t n_pad) {
   if (blockIdx.x == 0 && threadIdx.x < 4) tgt_local[n_pad + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);  // the read-ahead padding
   for (int64_t p = (int64_t)blockIdx.x * O3D_BLOCK + threadIdx.x; p < n_grid; p += (int64_t)gridDim.x * O3D_BLOCK) {
     const uint32_t i = vals[p];
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
     q.z = xyz[3 * (size_t)i + 2];
     q.w = __longlong_as_double((long long)i);
     tgt_sorted[p] = q;
+    tgt_index[p] = i;
     {  // fp32 copy relative to the origin of the cell the point was filed under (same arithmetic as k_target_keys)
       const int cx = min(max(o3d_cell_coord(q.x, gp.gmin[0], gp.inv_h, gp.nx), 0), gp.nx - 1);
       const int cy = min(max(o3d_cell_coord(q.y, gp.gmin[1], gp.inv_h, gp.ny), 0), gp.ny - 1);
@@ -571,6 +572,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
     // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_index, &ctx->cap_tidx, sizeof(uint32_t) * (size_t)n));
     if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
     want_tn = dev_nrm && allow_bricks && !getenv("O3D_NO_TN");  // (the ICP set-up; the switch is a tuning aid)
     if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double2) * 3 * (size_t)n));
@@ -671,7 +673,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
           hipLaunchKernelGGL(k_cell_table<kCtCellsSmall>, dim3((unsigned)((ntab_c + kCtCellsSmall - 1) / kCtCellsSmall)), dim3(O3D_BLOCK),
                              0, ctx->stream, skeys, (uint32_t)n, ctx->cell_start, (uint64_t)ntab_c, mask);
         hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm, svals, nfinite, gp,
-                           ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr, ctx->tgt_local, tn_c ? ctx->tn_sorted : nullptr, n);
+                           ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr, ctx->tgt_local, tn_c ? ctx->tn_sorted : nullptr, ctx->tgt_index, n);
         O3D_HIP(ctx, hipGetLastError());
         return O3D_OK;
       }});
@@ -698,7 +700,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
   if (nfinite > 0)
     hipLaunchKernelGGL(k_gather_target, dim3(grid_for(nfinite)), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, dev_nrm,
                        (const uint32_t *)vals, nfinite, gp, ctx->tgt_sorted, dev_nrm ? ctx->nrm_sorted : nullptr,
-                       ctx->tgt_local, want_tn ? ctx->tn_sorted : nullptr, n);
+                       ctx->tgt_local, want_tn ? ctx->tn_sorted : nullptr, ctx->tgt_index, n);
   ctx->tn_valid = (want_tn && nfinite > 0) ? 1 : 0;
   O3D_HIP(ctx, hipGetLastError());
   return O3D_OK;
@@ -746,7 +748,11 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   // One or two key bits over a multiple of the 8-bit digit would cost a whole radix pass: they are dropped (two or four
   // neighbouring cells of the curve share a key and keep their given order; only the processing ORDER depends on the key).
   const int over = (3 * axis_bits) % 8;
-  const int drop = (3 * axis_bits > 8 && over >= 1 && over <= 2) ? over : 0;
+  int drop = (3 * axis_bits > 8 && over >= 1 && over <= 2) ? over : 0;
+  if (const char *e = getenv("O3D_SRC_KEY_BITS")) {  // tuning aid: a coarser processing order for fewer radix passes
+    const int want = atoi(e);
+    if (want >= 8 && 3 * axis_bits > want) drop = 3 * axis_bits - want;
+  }
   if (o3d_gang_sort *gs = ctx->gang_sort; gs && 3 * axis_bits - drop <= O3D_GANG_KEY_BITS && gs->jobs.size() < 64 &&
                                           gs->used + n <= (int64_t)gs->cap) {
     const int64_t off = gs->used;
@@ -763,7 +769,15 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     }});
     return O3D_OK;
   }
-  {  // the permutation must END in src_perm: with an odd number of radix passes it starts in the other buffer (no copy home)
+  if (3 * axis_bits - drop <= 32) {  // (the common case: 32-bit keys, two thirds of the bytes per radix pass)
+    const int bits = 3 * axis_bits - drop;
+    const bool odd = o3d_radix_sort_odd(bits);
+    uint32_t *k0 = (uint32_t *)(odd ? tkeys : keys), *k1 = (uint32_t *)(odd ? keys : tkeys);
+    uint32_t *v0 = odd ? (uint32_t *)tvals : ctx->src_perm, *v1 = odd ? ctx->src_perm : (uint32_t *)tvals;
+    hipLaunchKernelGGL(k_source_keys<uint32_t>, dim3(g), dim3(O3D_BLOCK), 0, ctx->stream, dev_xyz, n, ctx->gp, Tm, apply_init, axis_bits,
+                       drop, k0, v0, 0u);
+    O3D_TRY(o3d_radix_sort_u32(ctx, k0, v0, k1, v1, (uint32_t *)hist, n, bits, false));
+  } else {  // the permutation must END in src_perm: with an odd number of radix passes it starts in the other buffer (no copy home)
     const int bits = 3 * axis_bits - drop;
     const bool odd = o3d_radix_sort_odd(bits);
     uint64_t *k0 = (uint64_t *)(odd ? tkeys : keys), *k1 = (uint64_t *)(odd ? keys : tkeys);

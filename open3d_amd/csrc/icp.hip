@@ -287,6 +287,7 @@ struct PassArgs {
   const double *nrm;
   int stream;            // k_icp_cert: streaming loads and stores for the source, the match positions and the bounds
   const double2 *tn;     // point and normal side by side (three double2 per sorted target point: 48 bytes), or null
+  const uint32_t *tidx;  // original index of every sorted target point (what tgt[].w holds, as a dense 4-byte array)
   const uint32_t *cell_start;
   const IcpState *st;
   int32_t *corr;   // per processing position: target index, or -1 none
@@ -1166,7 +1167,9 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
     if (use_p) {
       if (TN) {  // (never with point-to-point: no normals)
         const double2 r0 = a.tn[3 * (size_t)bpos], r1 = a.tn[3 * (size_t)bpos + 1], r2 = a.tn[3 * (size_t)bpos + 2];
-        p_p = make_double4(r0.x, r0.y, r1.x, a.tgt[bpos].w);  // the original index rides in tgt_sorted only
+        // the original index from its own dense array: neighbouring winners share its sectors (out of tgt_sorted, 8 bytes at
+        // a stride of 32, every index cost a sector of its own)
+        p_p = make_double4(r0.x, r0.y, r1.x, __longlong_as_double((long long)a.tidx[bpos]));
         n0_p = r1.y; n1_p = r2.x; n2_p = r2.y;
       } else {
         p_p = a.tgt[bpos];
@@ -2199,6 +2202,7 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pa.ctr = ctx->counters;
   pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
   pa.tn = ctx->tn_valid ? ctx->tn_sorted : nullptr;
+  pa.tidx = ctx->tgt_index;
   {
     static const char *e = getenv("O3D_STREAM");  // tuning aid: 0 = k_icp_cert with ordinary loads and stores
     pa.stream = e ? (atoi(e) ? 1 : 0) : 1;

@@ -103,6 +103,8 @@ struct o3d_ctx {
   double2 *tn_sorted = nullptr;   // point and normal of a sorted target point side by side: {x, y}, {z, nx}, {ny, nz} -- what the
                                   // estimate's sums gather per correspondence, in ONE 48-byte record (three 16-byte loads)
   size_t cap_tn = 0;
+  uint32_t *tgt_index = nullptr;  // original index of every sorted target point (tgt_sorted[p].w as a dense array)
+  size_t cap_tidx = 0;
   int tn_valid = 0;               // tn_sorted belongs to the grid in the context
   float4 *tgt_local = nullptr;    // fp32 {x, y, z} relative to the point's own cell origin, w = bits(padded x cell index)
   size_t cap_local = 0;
