@@ -1196,7 +1196,7 @@ int o3d_registration_icp_batch(o3d_ctx *c, int64_t n_pairs, const double *const 
         int64_t need = 0;
         for (int k = 0; k < m; k++) need += std::max<int64_t>(n_src[base + k], 0) + std::max<int64_t>(n_tgt[base + k], 0);
         const size_t nh = 256 * o3d_sort_num_tiles(need > 0 ? need : 1);
-        const size_t hneed = nh + o3d_scan_num_blocks((int64_t)nh) + 8;
+        const size_t hneed = nh + o3d_scan_num_blocks((int64_t)nh) + 264;
         bool ok = need < ((int64_t)1 << 31);
         if (ok && ((size_t)need > gs->cap || hneed > gs->hist_cap)) {
           (void)hipStreamSynchronize(lead->own_stream);

@@ -213,7 +213,15 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_cell_table(const uint32_t *__rest
     }
     const uint64_t c = c0 + 4ull * (uint64_t)qi;
     if (c + 3 < ntab) {
-      *reinterpret_cast<uint4 *>(cell_start + c) = v;
+      // a table far larger than the caches (hundreds of MB: written once, read by later kernels) leaves with streaming
+      // stores -- 210 -> 160 us for the 844 MB table of the 10 M headline; smaller ones stay in the cache for their readers
+      if (ntab > (64ull << 20)) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 nv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<u32x4 *>(cell_start + c));
+      } else {
+        *reinterpret_cast<uint4 *>(cell_start + c) = v;
+      }
     } else {
       if (c < ntab) cell_start[c] = v.x;
       if (c + 1 < ntab) cell_start[c + 1] = v.y;
@@ -249,14 +257,16 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_gather_target(const double *__res
       l.w = __int_as_float(cx + 1);
       tgt_local[p] = l;
     }
-    if (nrm) {
-      nrm_sorted[3 * p] = nrm[3 * (size_t)i];
-      nrm_sorted[3 * p + 1] = nrm[3 * (size_t)i + 1];
-      nrm_sorted[3 * p + 2] = nrm[3 * (size_t)i + 2];
+    if (nrm) {  // one form or the other: the 48-byte records of the ICP loop, or plain normals
+      const double n0 = nrm[3 * (size_t)i], n1 = nrm[3 * (size_t)i + 1], n2 = nrm[3 * (size_t)i + 2];
       if (tn_sorted) {
         tn_sorted[3 * p] = make_double2(q.x, q.y);
-        tn_sorted[3 * p + 1] = make_double2(q.z, nrm[3 * (size_t)i]);
-        tn_sorted[3 * p + 2] = make_double2(nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2]);
+        tn_sorted[3 * p + 1] = make_double2(q.z, n0);
+        tn_sorted[3 * p + 2] = make_double2(n1, n2);
+      } else {
+        nrm_sorted[3 * p] = n0;
+        nrm_sorted[3 * p + 1] = n1;
+        nrm_sorted[3 * p + 2] = n2;
       }
     }
   }
@@ -573,9 +583,9 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_index, &ctx->cap_tidx, sizeof(uint32_t) * (size_t)n));
-    if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
     want_tn = dev_nrm && allow_bricks && !getenv("O3D_NO_TN");  // (the ICP set-up; the switch is a tuning aid)
     if (want_tn) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tn_sorted, &ctx->cap_tn, sizeof(double2) * 3 * (size_t)n));
+    else if (dev_nrm) O3D_TRY(o3d_reserve(ctx, (void **)&ctx->nrm_sorted, &ctx->cap_nrm, sizeof(double) * 3 * (size_t)n));
   }
   const size_t ntiles = o3d_sort_num_tiles(n > 0 ? n : 1);
   const size_t nh = 256 * ntiles;
@@ -593,7 +603,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
-    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 264), &hist));
     {
       const int bits = ceil_log2((uint64_t)gp.nxp * (uint64_t)gp.ny * (uint64_t)gp.nz + 1);
       const bool odd = o3d_radix_sort_odd(bits);
@@ -652,7 +662,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
     O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint32_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
-    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 264), &hist));
     const int key_bits = ceil_log2((uint64_t)gp.ncell + 1);
     if (o3d_gang_sort *gs = ctx->gang_sort; gs && nfinite > 0 && key_bits <= O3D_GANG_KEY_BITS && gs->jobs.size() < 64 &&
                                             gs->used + n <= (int64_t)gs->cap) {
@@ -739,7 +749,7 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
   O3D_TRY(o3d_scratch(ctx, 1, sizeof(uint64_t) * (size_t)n, &keys));
   O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
   O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
-  O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+  O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 264), &hist));
   InitT Tm;
   for (int i = 0; i < 16; i++) Tm.m[i] = init_colmajor[i];
   const int g = grid_for(n);

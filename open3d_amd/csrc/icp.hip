@@ -561,7 +561,12 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
       x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
       p = a.tgt[pos];
       if (EST != O3D_EST_POINT_TO_POINT) {
-        n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
+        if (a.tn) {  // (the set-up that wrote the 48-byte records wrote no separate normals)
+          const double2 r1 = a.tn[3 * (size_t)pos + 1], r2 = a.tn[3 * (size_t)pos + 2];
+          n0 = r1.y; n1 = r2.x; n2 = r2.y;
+        } else {
+          n0 = a.nrm[3 * (size_t)pos]; n1 = a.nrm[3 * (size_t)pos + 1]; n2 = a.nrm[3 * (size_t)pos + 2];
+        }
       }
       if (EST == O3D_EST_COLORED_ICP) { tc = a.tcol[pos]; is = a.sint[i]; }
       const double ddx = x - p.x, ddy = y - p.y, ddz = z - p.z;
@@ -2207,7 +2212,7 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
     static const char *e = getenv("O3D_STREAM");  // tuning aid: 0 = k_icp_cert with ordinary loads and stores
     pa.stream = e ? (atoi(e) ? 1 : 0) : 1;
   }
-  pa.nrm = ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
+  pa.nrm = ctx->tn_valid ? nullptr : ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
   pa.seed = ctx->use_seed;

@@ -1706,7 +1706,7 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
     O3D_TRY(o3d_scratch(ctx, 2, sizeof(uint32_t) * (size_t)n, &vals));
     O3D_TRY(o3d_scratch(ctx, 3, sizeof(uint64_t) * (size_t)n, &tkeys));
     O3D_TRY(o3d_scratch(ctx, 4, sizeof(uint32_t) * (size_t)n, &tvals));
-    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 8), &hist));
+    O3D_TRY(o3d_scratch(ctx, 5, sizeof(uint32_t) * (nh + o3d_scan_num_blocks((int64_t)nh) + 264), &hist));
     O3D_TRY(o3d_scratch(ctx, 6, sizeof(uint32_t) * (o3d_scan_num_blocks(n + 1) + 8), &bsum));
     O3D_TRY(o3d_scratch(ctx, 0, sizeof(uint32_t) * ((size_t)n + 8), &head));
     const int g = grid_for(n);

@@ -60,6 +60,31 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_hist(const KeyT *__restrict_
   hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// The digit-major table of per-tile counts, one workgroup per digit row: exclusive scan of the row in place, the row's total
+// to row_tot[digit].  The scatter kernel adds the totals of the lower digits itself (a 256-entry scan in LDS), so a radix
+// pass is three launches -- histogram, this, scatter -- instead of five (the device-wide scan was three by itself).
+__global__ __launch_bounds__(O3D_BLOCK) void k_sort_rowscan(uint32_t *__restrict__ hist, uint32_t *__restrict__ row_tot, uint32_t ntiles) {
+  __shared__ uint32_t wt[kWaves];
+  uint32_t *row = hist + (size_t)blockIdx.x * ntiles;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < ntiles; base += O3D_BLOCK * 4) {  // four consecutive tiles per thread
+    const uint32_t i = base + threadIdx.x * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = i + j < ntiles ? row[i + j] : 0u;
+    uint32_t tot;
+    const uint32_t ex = carry + block_exclusive_scan(v[0] + v[1] + v[2] + v[3], wt, &tot);
+    uint32_t run = ex;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i + j < ntiles) row[i + j] = run;
+      run += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) row_tot[blockIdx.x] = carry;
+}
+
 // FUSED (few tiles): the table holds the raw per-tile counts and every workgroup derives its 256 digit bases from them
 // itself (a row sum and a partial row sum per digit, one workgroup scan) -- three scan launches fewer per pass, which is
 // most of the time of a pass over a small cloud.
@@ -90,8 +115,11 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_sort_scatter(const KeyT *__restri
     }
     uint32_t all;
     gbase[threadIdx.x] = block_exclusive_scan(total, wt, &all) + mine;  // (ends with a workgroup barrier)
-  } else {
-    gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
+  } else {  // the row's own prefix (k_sort_rowscan) + the totals of the lower digits (behind the table)
+    __shared__ uint32_t wt2[kWaves];
+    uint32_t all;
+    const uint32_t lower = block_exclusive_scan(hist_scanned[(size_t)256 * ntiles + threadIdx.x], wt2, &all);
+    gbase[threadIdx.x] = lower + hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
   }
   __syncthreads();
 
@@ -239,7 +267,7 @@ int radix_sort_impl(o3d_ctx *ctx, KeyT *keys, uint32_t *vals, KeyT *tmp_keys, ui
   if (n >= (int64_t)1 << 31) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "radix sort: n=%lld exceeds 2^31-1", (long long)n);
   const uint32_t ntiles = (uint32_t)o3d_sort_num_tiles(n);
   const int64_t nh = (int64_t)256 * ntiles;
-  uint32_t *bsums = hist + nh;  // caller reserved o3d_scan_num_blocks(nh) + 1 extra words behind the table
+  uint32_t *bsums = hist + nh;  // the 256 row totals: callers reserve o3d_scan_num_blocks(nh) + 264 words behind the table
   KeyT *ka = keys, *kb = tmp_keys;
   uint32_t *va = vals, *vb = tmp_vals;
   int passes = (bits + 7) / 8;
@@ -251,7 +279,7 @@ int radix_sort_impl(o3d_ctx *ctx, KeyT *keys, uint32_t *vals, KeyT *tmp_keys, ui
       hipLaunchKernelGGL((k_sort_scatter<KeyT, true>), dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, va, kb, vb, hist, n,
                          shift, ntiles);
     } else {
-      O3D_TRY(o3d_exclusive_scan_u32(ctx, hist, bsums, nh));
+      hipLaunchKernelGGL(k_sort_rowscan, dim3(256), dim3(O3D_BLOCK), 0, ctx->stream, hist, bsums, ntiles);  // bsums = hist + 256 * ntiles
       hipLaunchKernelGGL((k_sort_scatter<KeyT, false>), dim3(ntiles), dim3(O3D_BLOCK), 0, ctx->stream, ka, va, kb, vb, hist, n,
                          shift, ntiles);
     }
