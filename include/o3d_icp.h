@@ -277,6 +277,47 @@ O3D_API int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double 
 O3D_API int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                          double *normals, int has_normals);
 
+/* ---- point clouds that stay in HBM across calls ------------------------------------------------------------------------
+ * The reference hands `const geometry::PointCloud &` from call to call (Registration.h:149-152, PointCloud.h:130,192):
+ * VoxelDownSample returns a cloud that EstimateNormals extends and RegistrationICP reads, all in the same memory.  Behind raw
+ * host pointers every one of those calls would move its clouds over PCIe again.  An o3d_cloud is the device-resident form of a
+ * PointCloud's points_ / normals_ / colors_ (PointCloud.h:330-334), owned by the library, on the device of the context it was
+ * created with; each function below is the entry point of the same name on such clouds (same kernels: results identical to
+ * the host-buffer call bit for bit).  Inputs are never modified (Registration.cpp:149 works on a copy), except that
+ * o3d_cloud_estimate_normals sets the cloud's normals as PointCloud::EstimateNormals does.  Results (transformation,
+ * correspondences, ...) go to HOST memory.  A cloud may be used with any context on its device, and with a multi context
+ * whose other devices can read that device's memory (o3d_ctx_create_multi). */
+typedef struct o3d_cloud o3d_cloud;
+/* nrm / col may be NULL.  The caller's buffers (`mem` space) are free when the call returns. */
+O3D_API int o3d_cloud_upload(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, int mem,
+                             o3d_cloud **out_cloud);
+O3D_API void o3d_cloud_free(o3d_cloud *cloud);
+O3D_API int64_t o3d_cloud_size(const o3d_cloud *cloud);
+O3D_API int o3d_cloud_has_normals(const o3d_cloud *cloud);
+O3D_API int o3d_cloud_has_colors(const o3d_cloud *cloud);
+/* device pointers (3 doubles per point; NULL when the cloud has no such attribute), valid until o3d_cloud_free */
+O3D_API const double *o3d_cloud_points(const o3d_cloud *cloud);
+O3D_API const double *o3d_cloud_normals(const o3d_cloud *cloud);
+O3D_API const double *o3d_cloud_colors(const o3d_cloud *cloud);
+/* host buffers of o3d_cloud_size entries each; any may be NULL */
+O3D_API int o3d_cloud_download(o3d_ctx *ctx, const o3d_cloud *cloud, double *out_xyz, double *out_nrm, double *out_col);
+/* PointCloud::VoxelDownSample, geometry/PointCloud.cpp:273-306: a new cloud (points, and normals / colours where the input
+ * has them) of exactly the voxel count, in ascending voxel index like o3d_voxel_down_sample. */
+O3D_API int o3d_cloud_voxel_down_sample(o3d_ctx *ctx, const o3d_cloud *in, double voxel_size, o3d_cloud **out_cloud);
+/* PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351, in place: existing normals orient the new ones (:343-346). */
+O3D_API int o3d_cloud_estimate_normals(o3d_ctx *ctx, o3d_cloud *cloud, int search_type, int knn, double radius);
+/* RegistrationICP, Registration.cpp:129-168, as o3d_registration_icp; the target's normals are the cloud's.  out_corr: HOST,
+ * o3d_cloud_size(source) entries, may be NULL. */
+O3D_API int o3d_cloud_registration_icp(o3d_ctx *ctx, const o3d_cloud *source, const o3d_cloud *target,
+                                       double max_correspondence_distance, const double init_colmajor[16], int estimation,
+                                       int with_scaling, double relative_fitness, double relative_rmse, int max_iteration,
+                                       double out_transformation[16], int32_t *out_corr, int64_t *out_n_corr, double *out_fitness,
+                                       double *out_inlier_rmse, int *out_iterations);
+/* EvaluateRegistration, Registration.cpp:118-127, as o3d_evaluate_registration. */
+O3D_API int o3d_cloud_evaluate_registration(o3d_ctx *ctx, const o3d_cloud *source, const o3d_cloud *target,
+                                            double max_correspondence_distance, const double transformation_colmajor[16],
+                                            int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_inlier_rmse);
+
 /* ---- the other KDTreeFlann consumers on point clouds ------ */
 
 /* PointCloud::ComputePointCloudDistance, geometry/PointCloud.cpp:112-132: out_dist[i] = distance from source point i to its

@@ -108,6 +108,22 @@ _SIGNATURES = {
     "o3d_set_fast_normal_computation": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                        C.c_int]),
+    "o3d_cloud_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "o3d_cloud_free": (None, [C.c_void_p]),
+    "o3d_cloud_size": (C.c_int64, [C.c_void_p]),
+    "o3d_cloud_has_normals": (C.c_int, [C.c_void_p]),
+    "o3d_cloud_has_colors": (C.c_int, [C.c_void_p]),
+    "o3d_cloud_points": (C.c_void_p, [C.c_void_p]),
+    "o3d_cloud_normals": (C.c_void_p, [C.c_void_p]),
+    "o3d_cloud_colors": (C.c_void_p, [C.c_void_p]),
+    "o3d_cloud_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "o3d_cloud_voxel_down_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "o3d_cloud_estimate_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]),
+    "o3d_cloud_registration_icp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, c_dp, C.c_int, C.c_int, C.c_double,
+                                             C.c_double, C.c_int, c_dp, C.c_void_p, C.POINTER(C.c_int64), c_dp, c_dp,
+                                             C.POINTER(C.c_int)]),
+    "o3d_cloud_evaluate_registration": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, c_dp, C.c_void_p,
+                                                  C.POINTER(C.c_int64), c_dp, c_dp]),
 }
 
 _lib = None

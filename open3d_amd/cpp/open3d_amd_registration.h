@@ -527,6 +527,115 @@ inline RegistrationResult RegistrationICP(const o3d_types::PointCloud &source, c
   return result;
 }
 
+// ---- clouds that stay in HBM across calls (o3d_cloud, include/o3d_icp.h) ------------------------------------------------
+// The reference passes `const PointCloud &` from VoxelDownSample to EstimateNormals to RegistrationICP in one address space;
+// through host pointers every call would cross PCIe again.  A DeviceCloud is uploaded once and down-sampled, given normals
+// and registered where it lies; results equal those of the PointCloud overloads bit for bit.
+class DeviceCloud {
+ public:
+  DeviceCloud() = default;
+  explicit DeviceCloud(const o3d_types::PointCloud &cloud, Context &c = Context::Default()) : ctx_(&c) {
+    Check(c.get(), o3d_cloud_upload(c.get(), (const double *)cloud.points_.data(),
+                                    cloud.HasNormals() ? (const double *)cloud.normals_.data() : nullptr,
+                                    cloud.HasColors() ? (const double *)cloud.colors_.data() : nullptr, (int64_t)cloud.points_.size(),
+                                    O3D_MEM_HOST, &h_));
+  }
+  ~DeviceCloud() { o3d_cloud_free(h_); }
+  DeviceCloud(const DeviceCloud &) = delete;
+  DeviceCloud &operator=(const DeviceCloud &) = delete;
+  DeviceCloud(DeviceCloud &&o) noexcept : h_(o.h_), ctx_(o.ctx_) { o.h_ = nullptr; }
+  DeviceCloud &operator=(DeviceCloud &&o) noexcept {
+    if (this != &o) { o3d_cloud_free(h_); h_ = o.h_; ctx_ = o.ctx_; o.h_ = nullptr; }
+    return *this;
+  }
+  size_t size() const { return (size_t)o3d_cloud_size(h_); }
+  bool HasNormals() const { return o3d_cloud_has_normals(h_) != 0; }
+  o3d_cloud *get() const { return h_; }
+  // PointCloud::VoxelDownSample, geometry/PointCloud.cpp:273-306
+  DeviceCloud VoxelDownSample(double voxel_size) const {
+    DeviceCloud out;
+    out.ctx_ = ctx_;
+    Check(ctx_->get(), o3d_cloud_voxel_down_sample(ctx_->get(), h_, voxel_size, &out.h_));
+    return out;
+  }
+  // PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351
+  void EstimateNormals(const o3d_types::KDTreeSearchParam &param = o3d_types::KDTreeSearchParamKNN(), bool fast_normal_computation = true) {
+    Check(ctx_->get(), o3d_set_fast_normal_computation(ctx_->get(), fast_normal_computation ? 1 : 0));
+    int type = (int)param.GetSearchType(), knn = 0;
+    double radius = 0.0;
+    if (type == O3D_SEARCH_KNN) knn = static_cast<const o3d_types::KDTreeSearchParamKNN &>(param).knn_;
+    else if (type == O3D_SEARCH_RADIUS) radius = static_cast<const o3d_types::KDTreeSearchParamRadius &>(param).radius_;
+    else {
+      radius = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).radius_;
+      knn = static_cast<const o3d_types::KDTreeSearchParamHybrid &>(param).max_nn_;
+    }
+    Check(ctx_->get(), o3d_cloud_estimate_normals(ctx_->get(), h_, type, knn, radius));
+  }
+  o3d_types::PointCloud Download() const {
+    o3d_types::PointCloud out;
+    const size_t n = size();
+    out.points_.resize(n);
+    if (HasNormals()) out.normals_.resize(n);
+    if (o3d_cloud_has_colors(h_)) out.colors_.resize(n);
+    Check(ctx_->get(), o3d_cloud_download(ctx_->get(), h_, (double *)out.points_.data(),
+                                          out.normals_.empty() ? nullptr : (double *)out.normals_.data(),
+                                          out.colors_.empty() ? nullptr : (double *)out.colors_.data()));
+    return out;
+  }
+  Context &context() const { return *ctx_; }
+
+ private:
+  o3d_cloud *h_ = nullptr;
+  Context *ctx_ = nullptr;
+};
+
+// RegistrationICP, Registration.cpp:129-168, on device-resident clouds (point-to-point / point-to-plane).
+inline RegistrationResult RegistrationICP(const DeviceCloud &source, const DeviceCloud &target, double max_correspondence_distance,
+                                          const o3d_types::Mat4 &init = o3d_types::Mat4::Identity(),
+                                          const TransformationEstimation &estimation = TransformationEstimationPointToPoint(false),
+                                          const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria()) {
+  if (!IsAccelerated(estimation)) throw std::runtime_error("open3d_amd: device-resident clouds take the point-to-point and point-to-plane estimations");
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  int with_scaling = 0;
+  if (!p2l) with_scaling = static_cast<const TransformationEstimationPointToPoint &>(estimation).with_scaling_ ? 1 : 0;
+  RegistrationResult result(init);
+  std::vector<int32_t> corr(source.size());
+  int64_t nc = 0;
+  int iters = 0;
+  double T[16];
+  o3d_ctx *c = source.context().get();
+  Check(c, o3d_cloud_registration_icp(c, source.get(), target.get(), max_correspondence_distance, init.data(),
+                                      p2l ? O3D_EST_POINT_TO_PLANE : O3D_EST_POINT_TO_POINT, with_scaling, criteria.relative_fitness_,
+                                      criteria.relative_rmse_, criteria.max_iteration_, T, corr.data(), &nc, &result.fitness_,
+                                      &result.inlier_rmse_, &iters));
+  for (int i = 0; i < 16; i++) result.transformation_.data()[i] = T[i];
+  detail::ExpandCorrespondences(corr, result.correspondence_set_);
+  return result;
+}
+
+// Coarse-to-fine registration (BASELINE configs 3 and 4; build-defined: the reference has no multi-scale function, this is the
+// loop a caller writes over its three calls).  Per scale v: VoxelDownSample(v) of both clouds, EstimateNormals(Hybrid(2 v, 30))
+// of the target for point-to-plane, RegistrationICP with max distance 2 v from the previous scale's transformation.  ONE upload
+// per raw cloud; everything else happens in HBM.
+inline std::vector<RegistrationResult> MultiScaleICP(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
+                                                     const std::vector<double> &voxel_sizes,
+                                                     const o3d_types::Mat4 &init = o3d_types::Mat4::Identity(),
+                                                     const TransformationEstimation &estimation = TransformationEstimationPointToPlane(),
+                                                     const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria(),
+                                                     Context &c = Context::Default()) {
+  const bool p2l = estimation.GetTransformationEstimationType() == TransformationEstimationType::PointToPlane;
+  DeviceCloud d_src(source, c), d_tgt(target, c);
+  std::vector<RegistrationResult> results;
+  o3d_types::Mat4 T = init;
+  for (double v : voxel_sizes) {
+    DeviceCloud sv = d_src.VoxelDownSample(v), tv = d_tgt.VoxelDownSample(v);
+    if (p2l) tv.EstimateNormals(o3d_types::KDTreeSearchParamHybrid(2.0 * v, 30));
+    results.push_back(RegistrationICP(sv, tv, 2.0 * v, T, estimation, criteria));
+    T = results.back().transformation_;
+  }
+  return results;
+}
+
 // RegistrationColoredICP, ColoredICP.cpp:205-211 (colour gradients :68-123 and the two-row estimation :125-177 on the device)
 inline RegistrationResult RegistrationColoredICP(const o3d_types::PointCloud &source, const o3d_types::PointCloud &target,
                                                  double max_distance, const o3d_types::Mat4 &init = o3d_types::Mat4::Identity(),

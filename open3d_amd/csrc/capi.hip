@@ -35,7 +35,8 @@ int o3d_launch_color_gather(o3d_ctx *ctx, const double *d_tgt_col, const double 
 int o3d_color_gradient_impl(o3d_ctx *ctx, const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double radius,
                             int max_nn, double *d_grad);
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
-                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m);
+                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m,
+                               double **own_out = nullptr);
 int o3d_estimate_normals_shard_impl(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                                     const double *oriented, int shard, int n_shards, double *out_part, int64_t *out_ng);
 int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t n, const double *all_parts, int n_shards, int mem,
@@ -983,8 +984,9 @@ struct HostBarrier {
 static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_t n_src, const double *tgt_xyz, const double *tgt_nrm,
                                   int64_t n_tgt, double max_dist, const double init[16], int estimation, int with_scaling,
                                   double rel_fitness, double rel_rmse, int max_iter, int mem, double out_T[16], int32_t *out_corr,
-                                  int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+                                  int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters, int out_mem = -1) {
   const int G = (int)m->ranks.size();
+  if (out_mem < 0) out_mem = mem;  // (o3d_cloud_registration_icp: device-resident clouds, results to the host)
   if (n_src < 0 || max_iter < 0) return o3d_fail(m, O3D_ERR_INVALID_ARG, "bad sizes");
   // Ranks on the SAME device (a rehearsal of the sharded path on one GPU) enqueue on one stream, that of the first of
   // them: behind the host barrier every rank's sums are then ahead of every rank's solve in stream order, and no event is
@@ -1050,7 +1052,7 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
     }
     // results: the transformation / fitness / rmse are the same on every rank; the correspondences are the rank's shard
     if (st == O3D_OK && !any_failed)
-      st = o3d_icp_finish(c, mem, r == 0 ? out_T : nullptr, out_corr ? out_corr + lo : nullptr, r == 0 ? out_n_corr : nullptr,
+      st = o3d_icp_finish(c, out_mem, r == 0 ? out_T : nullptr, out_corr ? out_corr + lo : nullptr, r == 0 ? out_n_corr : nullptr,
                           r == 0 ? out_fitness : nullptr, r == 0 ? out_rmse : nullptr, r == 0 ? out_iters : nullptr);
     else if (c->stream)
       (void)hipStreamSynchronize(c->stream);
@@ -2132,6 +2134,147 @@ int o3d_debug_copy_check(o3d_ctx *ctx, size_t bytes, int rounds, int64_t *out_mi
   if (da) (void)hipFree(da);
   if (db) (void)hipFree(db);
   return st;
+}
+
+}  // extern "C"
+
+// ---- clouds that stay in HBM across calls --------------------------------------------------------------------------------
+// The reference passes `const PointCloud &` from call to call (Registration.h:149-152, PointCloud.h:130,192); behind a C ABI of
+// raw host pointers every call would upload its clouds again -- config 3 from host buffers moved 2 x 240 MB three times, config
+// 4 three times 2 x 2.4 GB.  An o3d_cloud is a PointCloud's points_ / normals_ / colors_ (PointCloud.h:330-334) in device
+// memory owned by the library: uploaded once, down-sampled / given normals / registered without leaving the GPU.  The entry
+// points are the existing ones with mem = O3D_MEM_DEVICE underneath, so every result is the host-buffer call's bit for bit.
+struct o3d_cloud {
+  int device = 0;
+  int64_t n = 0;
+  double *xyz = nullptr, *nrm = nullptr, *col = nullptr;
+};
+
+extern "C" {
+
+void o3d_cloud_free(o3d_cloud *c) {
+  if (!c) return;
+  DeviceGuard guard(c->device);
+  for (double *p : {c->xyz, c->nrm, c->col})
+    if (p) (void)hipFree(p);
+  delete c;
+}
+
+int o3d_cloud_upload(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, int mem, o3d_cloud **out) {
+  if (!ctx || !out || n < 0 || (n > 0 && !xyz)) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "o3d_cloud_upload: bad sizes or null buffers");
+  *out = nullptr;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  o3d_cloud *c = new (std::nothrow) o3d_cloud();
+  if (!c) return O3D_ERR_OOM;
+  c->device = ctx->device;
+  c->n = n;
+  const size_t bytes = sizeof(double) * 3 * (size_t)(n > 0 ? n : 1);
+  const double *in[3] = {xyz, nrm, col};
+  double **dst[3] = {&c->xyz, &c->nrm, &c->col};
+  for (int k = 0; k < 3; k++) {
+    if (!in[k] && k > 0) continue;
+    hipError_t e = hipMalloc((void **)dst[k], bytes);
+    if (e == hipSuccess && n > 0)
+      e = mem == O3D_MEM_DEVICE ? hipMemcpyAsync(*dst[k], in[k], sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream)
+                                : o3d_h2d(ctx, *dst[k], in[k], sizeof(double) * 3 * (size_t)n);
+    if (e != hipSuccess) {
+      o3d_cloud_free(c);
+      return o3d_fail(ctx, e == hipErrorOutOfMemory ? O3D_ERR_OOM : O3D_ERR_HIP, "o3d_cloud_upload: %s", hipGetErrorString(e));
+    }
+  }
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffers are free when this returns
+  *out = c;
+  return O3D_OK;
+}
+
+int64_t o3d_cloud_size(const o3d_cloud *c) { return c ? c->n : 0; }
+int o3d_cloud_has_normals(const o3d_cloud *c) { return c && c->nrm && c->n > 0; }
+int o3d_cloud_has_colors(const o3d_cloud *c) { return c && c->col && c->n > 0; }
+const double *o3d_cloud_points(const o3d_cloud *c) { return c ? c->xyz : nullptr; }
+const double *o3d_cloud_normals(const o3d_cloud *c) { return c ? c->nrm : nullptr; }
+const double *o3d_cloud_colors(const o3d_cloud *c) { return c ? c->col : nullptr; }
+
+int o3d_cloud_download(o3d_ctx *ctx, const o3d_cloud *c, double *out_xyz, double *out_nrm, double *out_col) {
+  if (!ctx || !c) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
+  if (c->n > 0) {
+    if (out_xyz) O3D_HIP(ctx, o3d_d2h(ctx, out_xyz, c->xyz, bytes));
+    if (out_nrm && c->nrm) O3D_HIP(ctx, o3d_d2h(ctx, out_nrm, c->nrm, bytes));
+    if (out_col && c->col) O3D_HIP(ctx, o3d_d2h(ctx, out_col, c->col, bytes));
+  }
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
+int o3d_cloud_voxel_down_sample(o3d_ctx *ctx, const o3d_cloud *in, double voxel_size, o3d_cloud **out) {
+  if (!ctx || !in || !out) return O3D_ERR_INVALID_ARG;
+  *out = nullptr;
+  O3D_LOCK(ctx);
+  DeviceGuard guard(ctx->device);
+  o3d_cloud *c = new (std::nothrow) o3d_cloud();
+  if (!c) return O3D_ERR_OOM;
+  c->device = ctx->device;
+  double *own[3] = {nullptr, nullptr, nullptr};
+  int64_t m = 0;
+  const int st = o3d_voxel_down_sample_impl(ctx, in->xyz, in->nrm, in->col, in->n, voxel_size, O3D_MEM_DEVICE, nullptr, nullptr, nullptr,
+                                            nullptr, &m, own);
+  if (st != O3D_OK) { delete c; return st; }
+  c->n = m;
+  c->xyz = own[0]; c->nrm = own[1]; c->col = own[2];
+  if (!c->xyz) {  // an empty cloud (or one without a finite point): still a valid handle
+    if (hipMalloc((void **)&c->xyz, 256) != hipSuccess) { delete c; return o3d_fail(ctx, O3D_ERR_OOM, "o3d_cloud_voxel_down_sample"); }
+    c->n = 0;
+  }
+  *out = c;
+  return O3D_OK;
+}
+
+int o3d_cloud_estimate_normals(o3d_ctx *ctx, o3d_cloud *c, int search_type, int knn, double radius) {
+  if (!ctx || !c) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  const int had = c->nrm != nullptr;
+  if (!had) {
+    DeviceGuard guard(ctx->device);
+    O3D_HIP(ctx, hipMalloc((void **)&c->nrm, sizeof(double) * 3 * (size_t)(c->n > 0 ? c->n : 1)));
+  }
+  if (c->n == 0) return O3D_OK;
+  const int st = o3d_estimate_normals(ctx, c->xyz, c->n, search_type, knn, radius, O3D_MEM_DEVICE, c->nrm, had);
+  if (st == O3D_OK) {  // (device memory: the call returns with its kernels enqueued)
+    DeviceGuard guard(ctx->device);
+    O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return st;
+}
+
+int o3d_cloud_registration_icp(o3d_ctx *ctx, const o3d_cloud *src, const o3d_cloud *tgt, double max_dist, const double init[16],
+                               int estimation, int with_scaling, double rel_fitness, double rel_rmse, int max_iter, double out_T[16],
+                               int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_rmse, int *out_iters) {
+  if (!ctx || !src || !tgt) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);  // held for the whole call
+  if (static_cast<o3d_ctx_full *>(ctx)->ranks.size() > 1)
+    return multi_registration_icp(static_cast<o3d_ctx_full *>(ctx), src->xyz, src->n, tgt->xyz, tgt->nrm, tgt->n, max_dist, init, estimation,
+                                  with_scaling, rel_fitness, rel_rmse, max_iter, O3D_MEM_DEVICE, out_T, out_corr, out_n_corr, out_fitness,
+                                  out_rmse, out_iters, O3D_MEM_HOST);
+  DeviceGuard guard(ctx->device);
+  O3D_TRY(o3d_icp_setup(ctx, src->xyz, src->n, tgt->xyz, tgt->nrm, tgt->n, max_dist, init, estimation, with_scaling, rel_fitness, rel_rmse,
+                        max_iter, O3D_MEM_DEVICE, src->n));
+  O3D_TRY(run_icp_loop(ctx, max_iter));
+  return o3d_icp_finish(ctx, O3D_MEM_HOST, out_T, out_corr, out_n_corr, out_fitness, out_rmse, out_iters);
+}
+
+int o3d_cloud_evaluate_registration(o3d_ctx *ctx, const o3d_cloud *src, const o3d_cloud *tgt, double max_dist, const double T[16],
+                                    int32_t *out_corr, int64_t *out_n_corr, double *out_fitness, double *out_rmse) {
+  if (!ctx || !src || !tgt || !T) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (!(max_dist > 0.0))  // Registration.cpp:45-47: an empty result (host outputs)
+    return o3d_evaluate_registration(ctx, nullptr, src->n, nullptr, tgt->n, max_dist, T, O3D_MEM_HOST, out_corr, out_n_corr, out_fitness, out_rmse);
+  O3D_TRY(o3d_icp_setup(ctx, src->xyz, src->n, tgt->xyz, nullptr, tgt->n, max_dist, T, O3D_EST_POINT_TO_POINT, 0, 0.0, 0.0, 0, O3D_MEM_DEVICE,
+                        src->n));
+  O3D_TRY(o3d_icp_step(ctx));
+  return o3d_icp_finish(ctx, O3D_MEM_HOST, nullptr, out_corr, out_n_corr, out_fitness, out_rmse, nullptr);
 }
 
 }  // extern "C"

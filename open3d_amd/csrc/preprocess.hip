@@ -1645,11 +1645,17 @@ int o3d_estimate_normals_assemble_impl(o3d_ctx *ctx, const double *xyz, int64_t 
   return st;
 }
 
+// own_out (device memory only): instead of writing into caller buffers of n entries, the outputs are allocated here with
+// hipMalloc at their exact size -- the voxel count is known on the host before they are written -- and handed over in own_out[0..2]
+// (points, normals, colours; the caller frees them).
 int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nrm, const double *col, int64_t n, double voxel,
-                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m) {
+                               int mem, double *out_xyz, double *out_nrm, double *out_col, int32_t *out_vox, int64_t *out_m,
+                               double **own_out) {
   if (out_m) *out_m = 0;
+  if (own_out) own_out[0] = own_out[1] = own_out[2] = nullptr;
   if (!(voxel > 0.0)) return o3d_fail(ctx, O3D_ERR_VOXEL_SIZE, "%s", o3d_status_string(O3D_ERR_VOXEL_SIZE));  // :275-277
-  if (n < 0 || (n > 0 && (!xyz || !out_xyz)) || (nrm && !out_nrm) || (col && !out_col) || !out_m)
+  if (own_out && mem != O3D_MEM_DEVICE) return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "VoxelDownSample: library-owned outputs are device memory");
+  if (n < 0 || (n > 0 && (!xyz || (!out_xyz && !own_out))) || (nrm && !out_nrm && !own_out) || (col && !out_col && !own_out) || !out_m)
     return o3d_fail(ctx, O3D_ERR_INVALID_ARG, "VoxelDownSample: null buffer");
   if (n >= ((int64_t)1 << 31)) return o3d_fail(ctx, O3D_ERR_UNSUPPORTED, "VoxelDownSample: more than 2^31-1 points");
   if (n == 0) return O3D_OK;
@@ -1726,6 +1732,13 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
     uint32_t *seg_start = (uint32_t *)tvals;
     hipLaunchKernelGGL(k_segment_starts, dim3(grid_for(nf)), dim3(O3D_BLOCK), 0, ctx->stream, (const uint64_t *)keys,
                        (const uint32_t *)head, nf, seg_start);
+    if (own_out) {
+      const size_t ob = sizeof(double) * 3 * (size_t)(m > 0 ? m : 1);
+      O3D_HIP(ctx, hipMalloc((void **)&own_out[0], ob));
+      o_xyz = own_out[0];
+      if (nrm) { O3D_HIP(ctx, hipMalloc((void **)&own_out[1], ob)); o_nrm = own_out[1]; }
+      if (col) { O3D_HIP(ctx, hipMalloc((void **)&own_out[2], ob)); o_col = own_out[2]; }
+    }
     if (mem == O3D_MEM_HOST) {
       const size_t ob = sizeof(double) * 3 * (size_t)m;
       O3D_HIP(ctx, o3d_tmp_alloc(ctx, &stage[3], ob));
@@ -1751,6 +1764,11 @@ int o3d_voxel_down_sample_impl(o3d_ctx *ctx, const double *xyz, const double *nr
   };
   const int st = run();
   cleanup();
+  if (st != O3D_OK && own_out)
+    for (int k = 0; k < 3; k++) {
+      if (own_out[k]) (void)hipFree(own_out[k]);
+      own_out[k] = nullptr;
+    }
   return st;
 }
 

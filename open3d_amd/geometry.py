@@ -162,3 +162,73 @@ class PointCloud:
         indices = np.nonzero((avg > 0) & (avg < thr))[0]
         return self.SelectByIndex(indices), indices
 
+
+
+class DevicePointCloud:
+    """A PointCloud whose points_ / normals_ / colors_ stay in HBM across calls (o3d_cloud, include/o3d_icp.h): what the
+    reference gets for free by passing `const PointCloud &` from VoxelDownSample to EstimateNormals to RegistrationICP
+    (PointCloud.h:130,192, Registration.h:149-152).  Uploaded once; every method below is the PointCloud method of the same
+    name without a trip over PCIe.  Results are those of the host-buffer calls bit for bit."""
+
+    def __init__(self, handle, ctx):
+        self._h = handle
+        self.ctx = ctx
+
+    @classmethod
+    def upload(cls, cloud, ctx=None):
+        """From a PointCloud (or an (N, 3) array of points)."""
+        ctx = ctx or _lib.default_context()
+        if not isinstance(cloud, PointCloud):
+            cloud = PointCloud(cloud)
+        h = C.c_void_p()
+        ctx.check(ctx._lib.o3d_cloud_upload(ctx.handle, _lib.ptr(cloud.points_), _lib.ptr(cloud.normals_ if cloud.HasNormals() else None),
+                                            _lib.ptr(cloud.colors_ if cloud.HasColors() else None), len(cloud.points_), _lib.MEM_HOST,
+                                            C.byref(h)))
+        return cls(h, ctx)
+
+    def __len__(self):
+        return int(self.ctx._lib.o3d_cloud_size(self._h)) if self._h else 0
+
+    def HasPoints(self):
+        return len(self) > 0
+
+    def HasNormals(self):
+        return bool(self._h) and bool(self.ctx._lib.o3d_cloud_has_normals(self._h))
+
+    def HasColors(self):
+        return bool(self._h) and bool(self.ctx._lib.o3d_cloud_has_colors(self._h))
+
+    def VoxelDownSample(self, voxel_size, ctx=None):
+        """PointCloud::VoxelDownSample, geometry/PointCloud.cpp:273-306 -> a new DevicePointCloud."""
+        ctx = ctx or self.ctx
+        h = C.c_void_p()
+        ctx.check(ctx._lib.o3d_cloud_voxel_down_sample(ctx.handle, self._h, float(voxel_size), C.byref(h)))
+        return DevicePointCloud(h, ctx)
+
+    def EstimateNormals(self, search_param=None, fast_normal_computation=True, ctx=None):
+        """PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351, in place."""
+        ctx = ctx or self.ctx
+        ctx.check(ctx._lib.o3d_set_fast_normal_computation(ctx.handle, int(bool(fast_normal_computation))))
+        sp = search_param or KDTreeSearchParamKNN()
+        ctx.check(ctx._lib.o3d_cloud_estimate_normals(ctx.handle, self._h, sp.search_type, sp.knn_, sp.radius_))
+        return self
+
+    def download(self):
+        """-> PointCloud (host copies of whatever the cloud holds)."""
+        n = len(self)
+        pts = np.empty((n, 3))
+        nrm = np.empty((n, 3)) if self.HasNormals() else None
+        col = np.empty((n, 3)) if self.HasColors() else None
+        self.ctx.check(self.ctx._lib.o3d_cloud_download(self.ctx.handle, self._h, _lib.ptr(pts), _lib.ptr(nrm), _lib.ptr(col)))
+        return PointCloud(pts, nrm, col)
+
+    def free(self):
+        if self._h:
+            self.ctx._lib.o3d_cloud_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -109,13 +109,38 @@ def _pairs(corr):
     return out[:m]
 
 
+def _registration_icp_on_device_clouds(source, target, r, init, estimation, criteria, ctx, want_corr=True):
+    """RegistrationICP on DevicePointCloud handles (o3d_cloud_registration_icp): nothing but the result crosses PCIe."""
+    est = estimation.GetTransformationEstimationType()
+    if est not in (_lib.EST_POINT_TO_POINT, _lib.EST_POINT_TO_PLANE):
+        raise _lib.O3DError(9, "device-resident clouds take the point-to-point and point-to-plane estimations")
+    n = len(source)
+    T = np.zeros(16)
+    corr = np.empty(max(n, 1), np.int32) if want_corr else None
+    nc = C.c_int64()
+    fit, rmse = C.c_double(), C.c_double()
+    iters = C.c_int()
+    ctx.check(ctx._lib.o3d_cloud_registration_icp(ctx.handle, source._h, target._h, float(r), _lib.colmajor(init).ctypes.data_as(_lib.c_dp),
+                                                  est, int(getattr(estimation, "with_scaling_", False)), criteria.relative_fitness_,
+                                                  criteria.relative_rmse_, criteria.max_iteration_, T.ctypes.data_as(_lib.c_dp),
+                                                  _lib.ptr(corr), C.byref(nc), C.byref(fit), C.byref(rmse), C.byref(iters)))
+    res = RegistrationResult(_lib.from_colmajor(T))
+    if want_corr:
+        res.corr_ = corr[:n]
+        res.correspondence_set_ = _pairs(res.corr_)
+    res.fitness_, res.inlier_rmse_, res.iterations_, res.n_corr_ = fit.value, rmse.value, iters.value, nc.value
+    return res
+
+
 def RegistrationICP(source, target, max_correspondence_distance, init=None, estimation=None, criteria=None, ctx=None):
-    """RegistrationICP, Registration.cpp:129-168."""
+    """RegistrationICP, Registration.cpp:129-168.  source / target: PointCloud, or DevicePointCloud handles (both)."""
     ctx = ctx or _lib.default_context()
     init = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
     estimation = estimation or TransformationEstimationPointToPoint(False)
     criteria = criteria or ICPConvergenceCriteria()
     est = estimation.GetTransformationEstimationType()
+    if hasattr(source, "_h") and hasattr(target, "_h"):
+        return _registration_icp_on_device_clouds(source, target, max_correspondence_distance, init, estimation, criteria, ctx)
     if est not in (_lib.EST_POINT_TO_POINT, _lib.EST_POINT_TO_PLANE):
         return _registration_icp_host_estimation(source, target, max_correspondence_distance, init, estimation, criteria, ctx)
     src = np.ascontiguousarray(source.points_, dtype=np.float64)
@@ -483,19 +508,41 @@ def RegistrationColoredICP(source, target, max_distance, init=None, criteria=Non
 
 
 def MultiScaleICP(source, target, voxel_sizes, max_correspondence_distances=None, init=None, estimation=None,
-                  criteria=None, normal_radius_factor=2.0, normal_max_nn=30, ctx=None):
+                  criteria=None, normal_radius_factor=2.0, normal_max_nn=30, ctx=None, device_resident=True, want_corr=True):
     """Coarse-to-fine registration (BASELINE configs 3 and 4).  Build-defined: the reference has no multi-scale API; this
     is the loop a caller writes over its three calls -- per scale v: VoxelDownSample(v) on both clouds
     (PointCloud.cpp:273-306), EstimateNormals(Hybrid(normal_radius_factor * v, normal_max_nn)) on the target for
     point-to-plane (EstimateNormals.cpp:320-351), RegistrationICP with max distance 2 v (or the given one) starting from the
     previous scale's transformation (Registration.cpp:129-168).  voxel_size <= 0 uses the clouds as they are.
     Returns (final RegistrationResult, [per-scale RegistrationResult])."""
-    from ..geometry import KDTreeSearchParamHybrid
+    from ..geometry import DevicePointCloud, KDTreeSearchParamHybrid
     ctx = ctx or _lib.default_context()
     estimation = estimation or TransformationEstimationPointToPlane()
     T = np.eye(4) if init is None else np.asarray(init, dtype=np.float64)
     p2l = estimation.GetTransformationEstimationType() == _lib.EST_POINT_TO_PLANE
     results = []
+    if device_resident and estimation.GetTransformationEstimationType() in (_lib.EST_POINT_TO_POINT, _lib.EST_POINT_TO_PLANE):
+        # ONE upload per raw cloud; every scale's clouds are made and consumed in HBM (o3d_cloud_*): same results, bit for bit
+        d_src = source if hasattr(source, "_h") else DevicePointCloud.upload(source, ctx)
+        d_tgt = target if hasattr(target, "_h") else DevicePointCloud.upload(target, ctx)
+        for k, v in enumerate(voxel_sizes):
+            src_v = d_src.VoxelDownSample(v, ctx=ctx) if v > 0 else d_src
+            tgt_v = d_tgt.VoxelDownSample(v, ctx=ctx) if v > 0 else d_tgt
+            if p2l and not (v <= 0 and tgt_v.HasNormals()):
+                tgt_v.EstimateNormals(KDTreeSearchParamHybrid(normal_radius_factor * v, normal_max_nn), ctx=ctx)
+            r = max_correspondence_distances[k] if max_correspondence_distances is not None else 2.0 * v
+            crit = criteria[k] if isinstance(criteria, (list, tuple)) else (criteria or ICPConvergenceCriteria())
+            res = _registration_icp_on_device_clouds(src_v, tgt_v, r, T, estimation, crit, ctx, want_corr=want_corr)
+            res.n_source_, res.n_target_ = len(src_v), len(tgt_v)
+            results.append(res)
+            T = res.transformation_
+            for c in (src_v, tgt_v):
+                if c is not d_src and c is not d_tgt:
+                    c.free()
+        for c, given in ((d_src, source), (d_tgt, target)):
+            if c is not given:
+                c.free()
+        return results[-1], results
     for k, v in enumerate(voxel_sizes):
         src_v = source.VoxelDownSample(v, ctx=ctx) if v > 0 else source
         tgt_v = target.VoxelDownSample(v, ctx=ctx) if v > 0 else target

@@ -88,6 +88,21 @@ if "3" in which:  # config 3 pipeline: 10M raw -> VoxelDownSample(2 s) both -> E
                       "first_run_total_ms": first_ms}),
           flush=True)
 
+if "3h" in which:  # config 3 pipeline from host buffers through device-resident clouds: one upload per raw cloud
+    sc = synthetic.make_pair(10_000_000, 10_000_000, cfg_id=3)
+    s = sc["spacing"]
+    v = 2 * s
+    src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"])
+    ts = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        fin, per = reg.MultiScaleICP(src, tgt, [v], ctx=ctx)
+        ts.append(1e3 * (time.perf_counter() - t0))
+    print(json.dumps({"config": "3 (host buffers, device-resident clouds)", "what": "10M raw x2 uploaded once -> VoxelDownSample(2 s) x2 -> "
+                      "EstimateNormals(Hybrid(2 v, 30)) -> P2Plane ICP r = 2 v, default criteria; results (T, correspondences) to the host",
+                      "total_ms_per_repetition": ts, "n_after": [per[0].n_source_, per[0].n_target_], "iterations": fin.iterations_,
+                      "fitness": fin.fitness_}), flush=True)
+
 if "5" in which:  # config 5 in part: 64 pairs x 200k, P2Plane, criteria (0, 0, 30)
     npairs, n = 64, 200_000
     S, T_ = [], []

@@ -147,6 +147,25 @@ int main(int argc, char **argv) {
   for (int i = 0; i < 16; i++) put(out, rc.transformation_.m[i]);
   put(out, rc.fitness_); put(out, rc.inlier_rmse_); put(out, (double)rc.correspondence_set_.size());
 
+  // device-resident clouds: the two-scale chain (one upload per cloud) and, step by step, what it is made of
+  {
+    geometry::PointCloud bare;
+    bare.points_ = target.points_;
+    std::vector<reg::RegistrationResult> ms = reg::MultiScaleICP(source, bare, {2.0 * voxel, voxel});
+    if (ms.size() != 2) return 9;
+    for (const auto &x : ms) {
+      for (int i = 0; i < 16; i++) put(out, x.transformation_.m[i]);
+      put(out, x.fitness_); put(out, x.inlier_rmse_); put(out, (double)x.correspondence_set_.size());
+    }
+    reg::DeviceCloud dt(bare);
+    reg::DeviceCloud dv = dt.VoxelDownSample(voxel);
+    dv.EstimateNormals(geometry::KDTreeSearchParamHybrid(2.0 * voxel, 30));
+    geometry::PointCloud back = dv.Download();
+    put(out, (double)back.points_.size());
+    for (const auto &p : back.points_) { put(out, p(0)); put(out, p(1)); put(out, p(2)); }
+    for (const auto &p : back.normals_) { put(out, p(0)); put(out, p(1)); put(out, p(2)); }
+  }
+
   f = fopen(argv[2], "wb");
   if (!f) return 7;
   fwrite(out.data(), 8, out.size(), f);

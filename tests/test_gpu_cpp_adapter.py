@@ -103,6 +103,21 @@ def test_cpp_adapter_matches_python_mirror(ctx, oracle, tmp_path):
     assert out[o + 16] == cw2.fitness_ and out[o + 17] == cw2.inlier_rmse_ and int(out[o + 18]) == len(cw2.correspondence_set_)
     assert cw2.fitness_ > 0.9
     o += 19
+    # MultiScaleICP over device-resident clouds == the chain of host-buffer calls, bit for bit
+    T = np.eye(4)
+    bare = geometry.PointCloud(sc["target"])
+    for v in (2.0 * voxel, voxel):
+        sv, tv = src_pc.VoxelDownSample(v, ctx=ctx), bare.VoxelDownSample(v, ctx=ctx)
+        tv.EstimateNormals(geometry.KDTreeSearchParamHybrid(2.0 * v, 30), ctx=ctx)
+        w = reg.RegistrationICP(sv, tv, 2.0 * v, T, reg.TransformationEstimationPointToPlane(), ctx=ctx)
+        assert np.array_equal(out[o:o + 16].reshape(4, 4).T, w.transformation_)
+        assert out[o + 16] == w.fitness_ and out[o + 17] == w.inlier_rmse_ and int(out[o + 18]) == len(w.correspondence_set_)
+        T = w.transformation_
+        o += 19
+    m = int(out[o]); o += 1
+    assert m == len(tv.points_)
+    assert np.array_equal(out[o:o + 3 * m].reshape(-1, 3), tv.points_) and np.array_equal(out[o + 3 * m:o + 6 * m].reshape(-1, 3), tv.normals_)
+    o += 6 * m
     assert o == len(out)
 
 

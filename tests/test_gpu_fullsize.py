@@ -83,6 +83,7 @@ def test_config4_multiscale_100m_on_one_gpu(ctx, oracle):
     est = reg.TransformationEstimationPointToPlane()
     T = np.eye(4)
     sizes = []
+    chain_T = []
     for k, v in enumerate([0.05, 0.025, 0.0125]):
         sv, svox = source.VoxelDownSample(v, ctx=ctx, return_voxel_index=True)
         tv, tvox = target.VoxelDownSample(v, ctx=ctx, return_voxel_index=True)
@@ -117,5 +118,14 @@ def test_config4_multiscale_100m_on_one_gpu(ctx, oracle):
             assert np.array_equal(ev.corr_, got.corr_)
             assert ev.fitness_ == got.fitness_
         T = got.transformation_
+        chain_T.append((T.copy(), got.fitness_, got.inlier_rmse_, got.iterations_))
+    # the same chain as ONE call on device-resident clouds (o3d_cloud_*: one upload per raw cloud, every scale made and
+    # consumed in HBM): per scale the same transformation, fitness, rmse and iteration count, bit for bit
+    t1 = time.time()
+    fin, per = reg.MultiScaleICP(source, target, [0.05, 0.025, 0.0125], criteria=crit, ctx=ctx, want_corr=False)
+    print("config 4: MultiScaleICP on device-resident clouds from host buffers: %.2f s" % (time.time() - t1), flush=True)
+    for (Tk, fit, rmse, iters), r_ in zip(chain_T, per):
+        assert np.array_equal(r_.transformation_, Tk) and r_.fitness_ == fit and r_.inlier_rmse_ == rmse and r_.iterations_ == iters
+    assert [(r_.n_source_, r_.n_target_) for r_ in per] == [(a, b) for a, b, _ in sizes]
     assert 2_000_000 < sizes[0][0] < 2_500_000 and 8_000_000 < sizes[1][0] < 9_000_000 and 28_000_000 < sizes[2][0] < 32_000_000, sizes
     assert np.abs(T - T_true).max() < 2e-6, np.abs(T - T_true).max()
