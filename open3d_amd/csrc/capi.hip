@@ -1,5 +1,6 @@
 // C ABI of libo3d_amd.so (declared in include/o3d_icp.h): context management and the host-side driver of the
 // device-resident ICP loop (reference pipelines/registration/Registration.cpp:118-168).
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -228,6 +229,41 @@ const char *o3d_last_error(const o3d_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 }  // extern "C"
 
+// RCCL, bound at run time (dlopen): the library has no link-time dependency on it, and a process that has loaded a copy
+// already -- torch ships its own -- keeps using that one.  Only what the multi context needs: one communicator per listed
+// device in this process (ncclCommInitAll) and the all-gather of the ranks' 32 sums.
+namespace {
+typedef void *rcclComm_t;
+constexpr int kRcclDouble = 8;  // ncclFloat64 / ncclDouble (rccl.h)
+struct RcclApi {
+  int (*CommInitAll)(rcclComm_t *, int, const int *) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*CommAbort)(rcclComm_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const RcclApi &rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return a;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    a.ok = a.CommInitAll && a.CommDestroy && a.CommAbort && a.AllGather && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+
 struct o3d_ctx_full : o3d_ctx {
   std::recursive_mutex mu;  // one call in flight per context: concurrent callers of the same context are serialised
   o3d_staging stage;
@@ -237,6 +273,9 @@ struct o3d_ctx_full : o3d_ctx {
   double *mailbox = nullptr;            // pinned host memory mapped into every device: [parity][rank][32 sums]
   std::vector<double *> mailbox_dev;    // the same memory as each rank's device sees it
   std::vector<hipEvent_t> xev;          // [parity * G + rank]: the rank's sums of this parity are in the mailbox
+  // distinct devices: the exchange is an RCCL all-gather over xGMI on each rank's stream instead of the mailbox
+  std::vector<rcclComm_t> comms;        // one per rank (ncclCommInitAll), empty when the mailbox is in use
+  std::vector<double *> xsend, xrecv;   // per rank, on its device: its 32 sums / the G x 32 table
 };
 static o3d_staging *staging_of(o3d_ctx *ctx) { return &static_cast<o3d_ctx_full *>(ctx)->stage; }
 #define O3D_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock__(static_cast<o3d_ctx_full *>(ctx)->mu)
@@ -321,7 +360,9 @@ int o3d_ctx_create_multi(int n_devices, const int *device_ids, o3d_ctx **out_ctx
   if (n_devices < 1 || n_devices > 64 || !device_ids) return o3d_fail(nullptr, O3D_ERR_INVALID_ARG, "o3d_ctx_create_multi: 1..64 devices");
   o3d_ctx *first = nullptr;
   O3D_TRY(o3d_ctx_create(device_ids[0], &first));
-  if (n_devices == 1) { *out_ctx = first; return O3D_OK; }
+  // (O3D_MULTI_ONE_RANK=1: a "multi" context of ONE rank, which runs the whole sharded path -- communicator, all-gather,
+  // solve over the gathered table -- on a box with a single GPU; a test hook)
+  if (n_devices == 1 && !getenv("O3D_MULTI_ONE_RANK")) { *out_ctx = first; return O3D_OK; }
   o3d_ctx_full *ctx = static_cast<o3d_ctx_full *>(first);
   const int G = n_devices;
   auto bail = [&](int st, const char *what, hipError_t e) {
@@ -348,6 +389,31 @@ int o3d_ctx_create_multi(int n_devices, const int *device_ids, o3d_ctx **out_ctx
       if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(O3D_ERR_HIP, "hipDeviceEnablePeerAccess", e);
       (void)hipGetLastError();
     }
+  // The per-iteration exchange: an RCCL all-gather of 32 doubles per rank over xGMI when every rank has a GPU
+  // of its own; RCCL refuses a device listed twice, so the one-GPU rehearsal of the sharded path (and a process where RCCL
+  // cannot be loaded, O3D_NO_RCCL=1) exchanges through the pinned host mailbox below.
+  bool distinct = true;
+  for (int a = 0; a < G; a++)
+    for (int b = a + 1; b < G; b++)
+      if (device_ids[a] == device_ids[b]) distinct = false;
+  if (distinct && !getenv("O3D_NO_RCCL") && rccl_api().ok) {
+    ctx->comms.assign((size_t)G, nullptr);
+    const int rc = rccl_api().CommInitAll(ctx->comms.data(), G, device_ids);
+    if (rc != 0) {
+      ctx->comms.clear();
+      return bail(O3D_ERR_HIP, rccl_api().GetErrorString(rc), hipSuccess);
+    }
+    ctx->xsend.assign((size_t)G, nullptr);
+    ctx->xrecv.assign((size_t)G, nullptr);
+    for (int r = 0; r < G; r++) {
+      DeviceGuard g(device_ids[r]);
+      hipError_t e2 = hipMalloc((void **)&ctx->xsend[(size_t)r], sizeof(double) * O3D_NSUMS);
+      if (e2 == hipSuccess) e2 = hipMalloc((void **)&ctx->xrecv[(size_t)r], sizeof(double) * O3D_NSUMS * (size_t)G);
+      if (e2 != hipSuccess) return bail(O3D_ERR_HIP, "hipMalloc(exchange buffers)", e2);
+    }
+    *out_ctx = ctx;
+    return O3D_OK;
+  }
   hipError_t e = hipHostMalloc((void **)&ctx->mailbox, sizeof(double) * 2 * (size_t)G * O3D_NSUMS, hipHostMallocPortable | hipHostMallocMapped);
   if (e != hipSuccess) return bail(O3D_ERR_HIP, "hipHostMalloc(mailbox)", e);
   memset(ctx->mailbox, 0, sizeof(double) * 2 * (size_t)G * O3D_NSUMS);
@@ -383,6 +449,16 @@ void o3d_ctx_destroy(o3d_ctx *c) {
       (void)hipEventDestroy(ctx->xev[k]);
     }
   ctx->xev.clear();
+  for (size_t r = 0; r < ctx->comms.size(); r++)
+    if (ctx->comms[r]) (void)rccl_api().CommDestroy(ctx->comms[r]);
+  ctx->comms.clear();
+  for (size_t r = 0; r < ctx->xsend.size(); r++) {
+    DeviceGuard g(ctx->ranks[r]->device);
+    if (ctx->xsend[r]) (void)hipFree(ctx->xsend[r]);
+    if (ctx->xrecv[r]) (void)hipFree(ctx->xrecv[r]);
+  }
+  ctx->xsend.clear();
+  ctx->xrecv.clear();
   for (size_t r = 1; r < ctx->ranks.size(); r++) o3d_ctx_destroy(ctx->ranks[r]);
   ctx->ranks.clear();
   for (int g = 0; g < 2; g++)
@@ -988,11 +1064,84 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
   const int G = (int)m->ranks.size();
   if (out_mem < 0) out_mem = mem;  // (o3d_cloud_registration_icp: device-resident clouds, results to the host)
   if (n_src < 0 || max_iter < 0) return o3d_fail(m, O3D_ERR_INVALID_ARG, "bad sizes");
+  if (!m->comms.empty()) {
+    // One GPU per rank: pass -> RCCL all-gather of the 32 sums -> solve over the gathered table, all on the rank's stream.  The
+    // collective orders the ranks on the device; the host threads meet only before the loop (did every set-up succeed?) and,
+    // with stopping criteria, once per chunk of iterations to look at the loop's flag -- every rank computes bit-identical
+    // estimates from the same table, so every rank reads the same flag behind the same pass and takes the same decision.
+    for (rcclComm_t cm : m->comms)
+      if (!cm) return o3d_fail(m, O3D_ERR_STATE, "the context's communicator was aborted by an earlier failure: create a new context");
+    HostBarrier bar(G);
+    std::vector<int> status((size_t)G, O3D_OK);
+    const bool can_break = rel_fitness > 0.0 && rel_rmse > 0.0;
+    const int kChunk = 6;
+    auto work = [&](int r) {
+      o3d_ctx *c = m->ranks[(size_t)r];
+      std::unique_lock<std::recursive_mutex> lock(static_cast<o3d_ctx_full *>(c)->mu);
+      DeviceGuard guard(c->device);
+      const int64_t lo = n_src * r / G, hi = n_src * (r + 1) / G;
+      int st = o3d_icp_setup(c, src_xyz ? src_xyz + 3 * lo : nullptr, hi - lo, tgt_xyz, tgt_nrm, n_tgt, max_dist, init, estimation,
+                             with_scaling, rel_fitness, rel_rmse, max_iter, mem, n_src);
+      if (st == O3D_OK && can_break && !c->poll_ev && hipEventCreateWithFlags(&c->poll_ev, hipEventDisableTiming) != hipSuccess)
+        st = o3d_fail(c, O3D_ERR_HIP, "hipEventCreate");
+      bool go = bar.wait(st != O3D_OK ? 1 : 0) == 0;
+      volatile int *flag = reinterpret_cast<volatile int *>((char *)c->pinned + 3072);
+      bool pending = false, failed_here = false;
+      for (int it = 0; go && it <= max_iter; it++) {  // passes 0 .. max_iter (Registration.cpp:154-166)
+        if (st == O3D_OK) st = o3d_icp_pass_to(c, m->xsend[(size_t)r]);
+        if (st == O3D_OK) {
+          const int rc = rccl_api().AllGather(m->xsend[(size_t)r], m->xrecv[(size_t)r], O3D_NSUMS, kRcclDouble, m->comms[(size_t)r], c->stream);
+          if (rc != 0) st = o3d_fail(c, O3D_ERR_HIP, "ncclAllGather: %s", rccl_api().GetErrorString(rc));
+        }
+        if (st == O3D_OK) st = o3d_icp_solve(c, m->xrecv[(size_t)r], G);
+        if (it % kChunk == kChunk - 1 && it < max_iter) {
+          // a rank that failed has not enqueued its part of a collective: the others must not go on waiting for it
+          if (bar.wait(st != O3D_OK ? 1 : 0) != 0) { failed_here = true; break; }
+          if (can_break) {
+            if (pending) {
+              if (hipEventSynchronize(c->poll_ev) != hipSuccess) st = o3d_fail(c, O3D_ERR_HIP, "hipEventSynchronize");
+              else if (*flag) break;  // (the same value on every rank)
+            }
+            if (st == O3D_OK && (hipMemcpyAsync((void *)flag, &c->state->done, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                                 hipEventRecord(c->poll_ev, c->stream) != hipSuccess))
+              st = o3d_fail(c, O3D_ERR_HIP, "flag copy");
+            pending = true;
+          }
+        }
+      }
+      const bool all_ok = bar.wait(st != O3D_OK ? 1 : 0) == 0 && go && !failed_here;
+      if (!all_ok) (void)rccl_api().CommAbort(m->comms[(size_t)r]);  // frees kernels waiting for a rank that never came
+      if (st == O3D_OK && all_ok)
+        st = o3d_icp_finish(c, out_mem, r == 0 ? out_T : nullptr, out_corr ? out_corr + lo : nullptr, r == 0 ? out_n_corr : nullptr,
+                            r == 0 ? out_fitness : nullptr, r == 0 ? out_rmse : nullptr, r == 0 ? out_iters : nullptr);
+      else if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+      if (!all_ok) m->comms[(size_t)r] = nullptr;  // (aborted: the context exchanges nothing any more)
+      status[(size_t)r] = st != O3D_OK ? st : (all_ok ? O3D_OK : O3D_ERR_STATE);
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < G; r++) threads.emplace_back(work, r);
+    work(0);
+    for (auto &t : threads) t.join();
+    for (int r = 0; r < G; r++)
+      if (status[(size_t)r] != O3D_OK) {
+        if (r == 0 && status[0] != O3D_ERR_STATE) return status[0];
+        return o3d_fail(m, status[(size_t)r], "rank %d (device %d): %s", r, m->ranks[(size_t)r]->device, o3d_last_error(m->ranks[(size_t)r]));
+      }
+    return O3D_OK;
+  }
   // Ranks on the SAME device (a rehearsal of the sharded path on one GPU) enqueue on one stream, that of the first of
   // them: behind the host barrier every rank's sums are then ahead of every rank's solve in stream order, and no event is
   // needed between them.  (Cross-stream events between many streams of one device -- they share its four hardware queues
   // -- were seen to stall once in a long test process; between devices every stream has a queue of its own.)
   std::vector<int> leader((size_t)G, 0);
+  struct RestoreStreams {  // whatever way this function is left, every rank goes back to the stream of its own
+    o3d_ctx_full *m;
+    ~RestoreStreams() {
+      for (o3d_ctx *c : m->ranks) c->stream = c->own_stream_or_given;
+    }
+  } restore{m};
+  for (o3d_ctx *c : m->ranks) c->own_stream_or_given = c->stream;
   for (int r = 0; r < G; r++) {
     leader[(size_t)r] = r;
     for (int f = 0; f < r; f++)
@@ -1062,8 +1211,6 @@ static int multi_registration_icp(o3d_ctx_full *m, const double *src_xyz, int64_
   for (int r = 1; r < G; r++) threads.emplace_back(work, r);
   work(0);
   for (auto &t : threads) t.join();
-  for (int r = 1; r < G; r++)  // back to the streams of their own
-    if (leader[(size_t)r] != r) m->ranks[(size_t)r]->stream = m->ranks[(size_t)r]->own_stream;
   for (int r = 0; r < G; r++)
     if (status[(size_t)r] != O3D_OK) {
       if (r == 0) return status[0];  // its message is already on this context

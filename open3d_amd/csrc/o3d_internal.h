@@ -92,6 +92,7 @@ struct o3d_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream_or_given = nullptr;  // multi_registration_icp: the stream to return to after sharing a leader's
   std::string err;
 
   // target grid

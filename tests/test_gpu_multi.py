@@ -133,3 +133,51 @@ def test_multiscale_pipeline_on_multi_context(ctx, oracle):
             T = ref.transformation
     finally:
         m.close()
+
+
+def test_rccl_exchange_path_with_one_rank(oracle, tmp_path):
+    """With one GPU per rank the multi context exchanges its 32 sums per iteration through an RCCL all-gather on each rank's
+    stream (capi.hip, multi_registration_icp).  RCCL refuses a device listed twice, so on this one-GPU box the path is
+    rehearsed with ONE rank (O3D_MULTI_ONE_RANK=1 makes o3d_ctx_create_multi build a real multi context of one rank):
+    communicator from ncclCommInitAll, pass -> ncclAllGather -> solve over the gathered table, the chunked look at the loop's
+    flag -- against the ordinary context and the oracle.  In a process of its own: RCCL is loaded there and nowhere else.
+    N > 1 ranks over RCCL has not run anywhere."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        sys.path.insert(0, %r)
+        import oracle
+        from conftest import make_scene, rel_err
+        from open3d_amd import _lib, geometry
+        from open3d_amd.pipelines import registration as reg
+        sc = make_scene(200_000, 150_000, cfg_id=77, theta_deg=0.3)
+        s = sc["spacing"]
+        nrm = oracle.estimate_normals(sc["target"], oracle.HYBRID, 30, 4 * s)
+        src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm)
+        m = _lib.Context([0])
+        assert m._lib.o3d_ctx_num_devices(m.handle) == 1
+        one = _lib.Context(0)
+        for est, r, et in ((reg.TransformationEstimationPointToPlane(), 2 * s, 2), (reg.TransformationEstimationPointToPoint(), 3 * s, 1)):
+            for crit in (reg.ICPConvergenceCriteria(), reg.ICPConvergenceCriteria(0.0, 0.0, 14)):
+                a = reg.RegistrationICP(src, tgt, r, np.eye(4), est, crit, ctx=m)
+                b = reg.RegistrationICP(src, tgt, r, np.eye(4), est, crit, ctx=one)
+                ref = oracle.registration_icp(sc["source"], sc["target"], r, None, et, nrm, rel_fitness=crit.relative_fitness_,
+                                              rel_rmse=crit.relative_rmse_, max_iter=crit.max_iteration_)
+                assert a.iterations_ == b.iterations_ == ref.iterations, (a.iterations_, b.iterations_, ref.iterations)
+                assert np.array_equal(a.corr_, b.corr_) and np.array_equal(a.corr_, ref.corr)
+                assert rel_err(a.transformation_, b.transformation_) < 1e-12 and a.fitness_ == b.fitness_
+                assert rel_err(a.transformation_, ref.transformation) < 1e-6
+        d = geometry.DevicePointCloud.upload(src, m), geometry.DevicePointCloud.upload(tgt, m)
+        c = reg.RegistrationICP(d[0], d[1], 2 * s, np.eye(4), reg.TransformationEstimationPointToPlane(), ctx=m)
+        assert c.fitness_ > 0.99 and len(c.corr_) == len(sc["source"])
+        with open("/proc/self/maps") as f:
+            assert "librccl" in f.read(), "the exchange did not go through RCCL"
+        m.close(); one.close()
+        print("RCCL_ONE_RANK_OK")
+    """) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, O3D_MULTI_ONE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("O3D_NO_RCCL", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
