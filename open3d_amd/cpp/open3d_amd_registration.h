@@ -26,10 +26,14 @@
 #include "o3d_icp.h"
 
 #ifdef O3D_AMD_USE_OPEN3D_TYPES
+#ifdef O3D_AMD_OPEN3D_TYPES_HEADER  // (tests/cpp/compile_check.cpp: a types-only stub, for images without Eigen / Open3D)
+#include O3D_AMD_OPEN3D_TYPES_HEADER
+#else
 #include "open3d/geometry/KDTreeSearchParam.h"
 #include "open3d/geometry/PointCloud.h"
 #include "open3d/pipelines/registration/Registration.h"
 #include "open3d/pipelines/registration/TransformationEstimation.h"
+#endif
 #endif
 
 namespace open3d_amd {

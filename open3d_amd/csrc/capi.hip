@@ -20,10 +20,8 @@
 #include "o3d_internal.h"
 
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve);
-bool o3d_graph_eligible(o3d_ctx *ctx);
 bool o3d_gang_eligible(o3d_ctx *ctx);
 int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool upload, bool first);
-int o3d_graph_passes(o3d_ctx *ctx, bool first);
 int o3d_launch_solve(o3d_ctx *ctx, const double *dev_all_sums, int n_ranks);
 int o3d_launch_scatter_corr(o3d_ctx *ctx, int32_t *dev_out);
 int o3d_launch_info(o3d_ctx *ctx, double *dev_sums_out);
@@ -345,8 +343,6 @@ int o3d_ctx_create(int device_id, o3d_ctx **out_ctx) {
   if ((e = hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long) * O3D_NCOUNTERS, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
   if ((e = hipMalloc((void **)&ctx->gsums, sizeof(double) * O3D_NSUMS * 32 + sizeof(unsigned) * 64)) != hipSuccess) return bail(e, "hipMalloc gsums");
   ctx->tickets = reinterpret_cast<unsigned *>(ctx->gsums + O3D_NSUMS * 32);
-  if ((e = hipMalloc(&ctx->d_launch, 2048)) != hipSuccess) return bail(e, "hipMalloc pass arguments");
-  if ((e = hipHostMalloc(&ctx->pinned_launch, 2048, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
   if ((e = hipMemsetAsync(ctx->tickets, 0, sizeof(unsigned) * 64, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
   // the scratch address of o3d_compute_transformation_noalloc on this device, so that its first call may come under capture
   if (o3d_noalloc_prepare_device(device_id) != O3D_OK) return bail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
@@ -461,15 +457,13 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   ctx->xrecv.clear();
   for (size_t r = 1; r < ctx->ranks.size(); r++) o3d_ctx_destroy(ctx->ranks[r]);
   ctx->ranks.clear();
-  for (int g = 0; g < 2; g++)
-    if (ctx->graph_exec[g]) { (void)hipGraphExecDestroy(ctx->graph_exec[g]); ctx->graph_exec[g] = nullptr; }
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   ctx->mailbox = nullptr;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_launch,   ctx->d_gang, ctx->tgt_index};
+                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_gang, ctx->tgt_index};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -487,7 +481,6 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   o3d_tmp_release_all(ctx);
   o3d_xfer_destroy(ctx);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  if (ctx->pinned_launch) (void)hipHostFree(ctx->pinned_launch);
   if (ctx->pinned_gang) (void)hipHostFree(ctx->pinned_gang);
   if (ctx->gang_sort_own) {
     for (uint32_t *b : {ctx->gang_sort_own->keys, ctx->gang_sort_own->vals, ctx->gang_sort_own->tkeys, ctx->gang_sort_own->tvals,
@@ -643,10 +636,12 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
   if (ctx->use_cert && gs % 32 != 0) gs = (ctx->gang_slots > 1 && gs > 32) ? gs / 32 * 32 : (gs + 31) / 32 * 32;
   ctx->search_grid = (int)gs;
   ctx->use_tail = getenv("O3D_NO_TAIL") ? 0 : 1;  // tuning aid
-  // measured: no gain on ROCm 7.2 (a graph launch of eight kernel nodes costs the host what eight launches cost, and the
-  // batch of config 5 runs at the same 2230 pairs/s either way), so the plain launches stay the default
-  ctx->use_graph = getenv("O3D_GRAPH") ? 1 : 0;
-  ctx->launch_uploaded = 0;
+  {  // tuning aids, read per set-up like the others (a test can change them between registrations)
+    const char *e = getenv("O3D_STREAM");
+    ctx->use_stream = e ? (atoi(e) ? 1 : 0) : 1;
+    e = getenv("O3D_ONE_LAUNCH");
+    ctx->use_one_launch = (e && atoi(e) == 0) ? 0 : 1;
+  }
   if (const char *e = getenv("O3D_CERT_GAP")) {
     const double v = atof(e);
     if (v >= 0.0 && v <= 1.0) ctx->cert_gap = v;
@@ -754,7 +749,6 @@ int o3d_debug_set(o3d_ctx *ctx, int force_generic_pass, int collect_tile_stats) 
   O3D_LOCK(ctx);
   ctx->use_tile = force_generic_pass ? 0 : 1;
   ctx->tile_stats = collect_tile_stats;
-  ctx->launch_uploaded = 0;  // (both are arguments of the pass kernels)
   return O3D_OK;
 }
 
@@ -968,27 +962,6 @@ int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]) {
 static int run_icp_loop(o3d_ctx *ctx, int max_iter) {
   const int kChunk = 6;
   DeviceGuard guard(ctx->device);  // the event and the copy below belong to the context's device, whatever the caller's is
-  if (max_iter + 1 >= O3D_GRAPH_PASSES && o3d_graph_eligible(ctx)) {
-    // the loop as graph launches of O3D_GRAPH_PASSES passes (icp.hip); the done flag is looked at as below, a chunk late
-    const bool can_stop = ctx->rel_fitness > 0.0 && ctx->rel_rmse > 0.0;
-    if (can_stop && !ctx->poll_ev) O3D_HIP(ctx, hipEventCreateWithFlags(&ctx->poll_ev, hipEventDisableTiming));
-    volatile int *gflag = reinterpret_cast<volatile int *>((char *)ctx->pinned + 3072);
-    bool waiting = false;
-    for (int passes = 0; passes < max_iter + 1; passes += O3D_GRAPH_PASSES) {
-      ctx->enq_passes += O3D_GRAPH_PASSES;
-      ctx->sums_valid = 1;
-      O3D_TRY(o3d_graph_passes(ctx, passes == 0));
-      if (!can_stop || passes + O3D_GRAPH_PASSES >= max_iter + 1) continue;
-      if (waiting) {
-        O3D_HIP(ctx, hipEventSynchronize(ctx->poll_ev));
-        if (*gflag) break;
-      }
-      O3D_HIP(ctx, hipMemcpyAsync((void *)gflag, &ctx->state->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      O3D_HIP(ctx, hipEventRecord(ctx->poll_ev, ctx->stream));
-      waiting = true;
-    }
-    return O3D_OK;
-  }
   O3D_TRY(o3d_icp_step(ctx));
   // IcpState::done is set by the convergence test (:162-165: |d fitness| < relative_fitness AND |d rmse| < relative_rmse)
   // or at max_iteration: with a threshold that no absolute value is below, there is nothing to look for before the end.

@@ -920,8 +920,8 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
 }
 
-// The arguments of a pass's kernels as they sit in device memory for the graph form of the loop (o3d_graph_passes): a
-// graph whose kernel nodes take a pointer is instantiated once per context and serves every registration after it.
+// The arguments of a pass's kernels as they sit in device memory for the lock-step form of the loop (o3d_launch_pass_gang):
+// blockIdx.y picks the registration's record.
 struct PassLaunch {
   PassArgs a;
   GridParams gp;
@@ -936,11 +936,6 @@ template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_s(PassArgs a) {  // PassArgs::stream
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
   cert_body<EST, true>(a, lds_raw);
-}
-template <int EST>
-__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_ind(const PassLaunch *__restrict__ pl) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
-  cert_body<EST, false>(pl->a, lds_raw);
 }
 // ... and for several registrations in lock step (o3d_registration_icp_batch): blockIdx.y names the registration
 template <int EST>
@@ -1218,11 +1213,6 @@ template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop(PassArgs a, GridParams gp) {
   __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
   search_coop_body<EST, TN>(a, gp, wls);
-}
-template <int EST, bool TN>
-__global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_ind(const PassLaunch *__restrict__ pl) {
-  __shared__ CoopWave wls[O3D_BLOCK / O3D_WAVE];
-  search_coop_body<EST, TN>(pl->a, pl->gp, wls);
 }
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_search_coop_batch(const PassLaunch *__restrict__ pl) {
@@ -2208,10 +2198,7 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pa.src = ctx->src_sorted; pa.src_in = ctx->hyp_mode ? ctx->src_orig : ctx->src_sorted; pa.n_src = ctx->n_src; pa.tgt = ctx->tgt_sorted; pa.tgt_local = ctx->tgt_local;
   pa.tn = ctx->tn_valid ? ctx->tn_sorted : nullptr;
   pa.tidx = ctx->tgt_index;
-  {
-    static const char *e = getenv("O3D_STREAM");  // tuning aid: 0 = k_icp_cert with ordinary loads and stores
-    pa.stream = e ? (atoi(e) ? 1 : 0) : 1;
-  }
+  pa.stream = ctx->use_stream;
   pa.nrm = ctx->tn_valid ? nullptr : ctx->nrm_sorted; pa.cell_start = ctx->cell_start; pa.st = ctx->state; pa.corr = ctx->corr_sorted;
   pa.partials = ctx->partials; pa.thr = ctx->thr;
   pa.pos = ctx->pos_sorted;
@@ -2240,11 +2227,8 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pl.nparts = pa.listed ? 2 * pl.grows : pl.grows;
   // The search kernel's last workgroups add the partial rows and run the estimate themselves (pass_tail).
   pl.tail = pl.fused && ctx->use_tail;
-  {
-    static const char *e = getenv("O3D_ONE_LAUNCH");  // tuning aid: 0 = k_icp_cert and k_icp_search_coop as two launches
-    // (see k_icp_pass for the two conditions on the rows)
-    pl.one_launch = pl.fused && pl.tail && pa.listed && pa.stream && pa.cert_row0 % 32 == 0 && !(e && atoi(e) == 0);
-  }
+  // (see k_icp_pass for the two conditions on the rows)
+  pl.one_launch = pl.fused && pl.tail && pa.listed && pa.stream && pa.cert_row0 % 32 == 0 && ctx->use_one_launch;
   pa.tail = pl.tail ? (fuse_solve ? 2 : 1) : 0;
   pa.nparts = pl.nparts; pa.has_normals = ctx->has_tgt_normals; pa.log_rows = ctx->log_rows; pa.log = ctx->log;
   pa.tickets = ctx->tickets; pa.gsums = ctx->gsums; pa.sums_out = dev_sums_out; pa.st_rw = ctx->state;
@@ -2317,100 +2301,6 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
                        dev_sums_out);
 #undef O3D_LAUNCH_EST
   O3D_HIP(ctx, hipGetLastError());
-  return O3D_OK;
-}
-
-// ---- the loop as HIP graphs --------------------------------------------------------------------------------------------
-// A registration of a small cloud is a chain of short kernels, and what its host thread pays is launches: 3.7 us of HIP
-// runtime per kernel, serialised across the threads of a batch (o3d_registration_icp_batch: 0.2 ms per pair of 200 k
-// points, half of what a pair costs).  The pass kernels also exist in a form that reads its arguments from device memory
-// (PassLaunch), so ONE pair of graphs per context -- O3D_GRAPH_PASSES passes each, the first beginning with the unlisted
-// first pass -- is instantiated once and replayed by every registration whose kernels and grid are the same; a
-// registration then costs one small upload of the arguments and a graph launch per O3D_GRAPH_PASSES iterations.  Passes
-// enqueued beyond the end of the loop return at once (IcpState::done), as they always did.
-// MEASURED (ROCm 7.2, MI355X): no gain -- hipGraphLaunch of eight kernel nodes costs the host as much as eight launches
-// (0.130 against 0.118 ms for 31 passes) and the batch of config 5 runs at 2230 pairs/s either way.  The path is kept
-// behind O3D_GRAPH=1, bit-identical to the plain launches (tests/test_gpu_tail.py), for runtimes where graphs are cheaper.
-namespace {
-template <int EST, bool TN>
-void *search_ind_fn() { return reinterpret_cast<void *>(&k_icp_search_coop_ind<EST, TN>); }
-template <int EST>
-void *cert_ind_fn() { return reinterpret_cast<void *>(&k_icp_cert_ind<EST>); }
-}  // namespace
-
-bool o3d_graph_eligible(o3d_ctx *ctx) {
-  if (!ctx->use_graph || ctx->prof_on || ctx->hyp_mode) return false;
-  const bool fused = ctx->tile_ok && ctx->use_tile && ctx->gp.margin;
-  return fused && ctx->use_tail;
-}
-
-// Enqueues O3D_GRAPH_PASSES passes of the device-resident loop (pass + estimate each); first: the chunk begins with the
-// registration's first pass.
-int o3d_graph_passes(o3d_ctx *ctx, bool first) {
-  const PassPlan p0 = plan_pass(ctx, ctx->sums, 1, false), p1 = plan_pass(ctx, ctx->sums, 1, true);
-  if (!ctx->launch_uploaded) {
-    PassLaunch *h = reinterpret_cast<PassLaunch *>(ctx->pinned_launch);
-    static_assert(2 * sizeof(PassLaunch) <= 2048, "staging buffer of the pass arguments");
-    h[0].a = p0.pa; h[0].gp = ctx->gp;
-    h[1].a = p1.pa; h[1].gp = ctx->gp;
-    O3D_HIP(ctx, hipMemcpyAsync(ctx->d_launch, h, 2 * sizeof(PassLaunch), hipMemcpyHostToDevice, ctx->stream));
-    ctx->launch_uploaded = 1;
-  }
-  const int est = ctx->estimation;
-  const bool tn = p0.pa.tn != nullptr && est != O3D_EST_POINT_TO_POINT, cert = p1.pa.listed != 0;
-  const long long key = ((long long)p0.grows << 8) | (est << 4) | (tn ? 2 : 0) | (cert ? 1 : 0);
-  if (key != ctx->graph_key || !ctx->graph_exec[0]) {
-    for (int g = 0; g < 2; g++) {
-      if (ctx->graph_exec[g]) (void)hipGraphExecDestroy(ctx->graph_exec[g]);
-      ctx->graph_exec[g] = nullptr;
-    }
-    void *search_fn, *cert_fn;
-    if (est == O3D_EST_POINT_TO_PLANE) {
-      search_fn = tn ? search_ind_fn<O3D_EST_POINT_TO_PLANE, true>() : search_ind_fn<O3D_EST_POINT_TO_PLANE, false>();
-      cert_fn = cert_ind_fn<O3D_EST_POINT_TO_PLANE>();
-    } else if (est == O3D_EST_COLORED_ICP) {
-      search_fn = tn ? search_ind_fn<O3D_EST_COLORED_ICP, true>() : search_ind_fn<O3D_EST_COLORED_ICP, false>();
-      cert_fn = cert_ind_fn<O3D_EST_COLORED_ICP>();
-    } else {
-      search_fn = search_ind_fn<O3D_EST_POINT_TO_POINT, false>();
-      cert_fn = cert_ind_fn<O3D_EST_POINT_TO_POINT>();
-    }
-    const PassLaunch *d = reinterpret_cast<const PassLaunch *>(ctx->d_launch);
-    for (int g = 0; g < 2; g++) {
-      hipGraph_t graph;
-      O3D_HIP(ctx, hipGraphCreate(&graph, 0));
-      hipGraphNode_t prev = nullptr;
-      auto add = [&](void *fn, const PassLaunch *arg) -> hipError_t {
-        const PassLaunch *argv = arg;
-        void *params[] = {(void *)&argv};
-        hipKernelNodeParams kp{};
-        kp.func = fn;
-        kp.gridDim = dim3((unsigned)p0.grows);
-        kp.blockDim = dim3(O3D_BLOCK);
-        kp.sharedMemBytes = 0;
-        kp.kernelParams = params;
-        kp.extra = nullptr;
-        hipGraphNode_t node;
-        const hipError_t e = hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
-        prev = node;
-        return e;
-      };
-      hipError_t e = hipSuccess;
-      for (int k = 0; k < O3D_GRAPH_PASSES && e == hipSuccess; k++) {
-        const bool unlisted = g == 0 && k == 0;
-        if (!unlisted && cert) e = add(cert_fn, d + 1);
-        if (e == hipSuccess) e = add(search_fn, unlisted ? d : d + 1);
-      }
-      if (e == hipSuccess) e = hipGraphInstantiate(&ctx->graph_exec[g], graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) {
-        ctx->graph_key = -1;
-        O3D_HIP(ctx, e);
-      }
-    }
-    ctx->graph_key = key;
-  }
-  O3D_HIP(ctx, hipGraphLaunch(ctx->graph_exec[first ? 0 : 1], ctx->stream));
   return O3D_OK;
 }
 

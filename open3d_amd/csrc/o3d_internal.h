@@ -15,7 +15,6 @@
 #define O3D_NUM_CU 256
 #define O3D_MAX_GRID (O3D_NUM_CU * 8)  // memory-bound kernels: cap the grid and stride the rest
 #define O3D_NSUMS 32
-#define O3D_GRAPH_PASSES 8
 #define O3D_GANG_MAX 32  // registrations advancing in lock step (o3d_launch_pass_gang)
 
 // ---- sums layout (per pass, fp64) -------------------------------------------
@@ -117,13 +116,6 @@ struct o3d_ctx {
   uint32_t *brick_dir = nullptr;  // GridParams::dir of a bricked table
   size_t cap_dir = 0;
   int64_t n_bricks = 0;
-  // the loop as graphs (icp.hip, o3d_graph_passes)
-  int use_graph = 0;            // O3D_GRAPH=1 (plain launches by default: the graphs measured no gain)
-  void *d_launch = nullptr;     // two PassLaunch records in device memory: first pass, later passes
-  void *pinned_launch = nullptr;  // their staging buffer
-  int launch_uploaded = 0;      // ... holds the arguments of the current set-up
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};  // O3D_GRAPH_PASSES passes each: beginning with the first pass / later ones
-  long long graph_key = -1;     // kernels and grid the graphs were built for
   // several registrations in lock step (icp.hip, o3d_launch_pass_gang): the lead context's argument table
   void *d_gang = nullptr, *pinned_gang = nullptr;
   int gang_grid = 0, gang_cert = 0, gang_tn = 0, gang_stream = 0, gang_one_launch = 0;
@@ -171,6 +163,8 @@ struct o3d_ctx {
   int use_bricks = 1;   // sparse scenes get the bricked cell table (O3D_NO_BRICKS=1: coarser cells in a dense table instead)
   int use_tail = 1;     // the search kernel's last workgroups end the pass (O3D_NO_TAIL=1: separate finalize / solve launch)
   int use_cert = 1;     // k_icp_search_coop: certified previous matches skip the search (O3D_NO_CERT=1 turns it off)
+  int use_stream = 1;   // certificate half with streaming loads and stores (O3D_STREAM=0: ordinary ones; read per set-up)
+  int use_one_launch = 1;  // certificates and search of a pass in one launch, k_icp_pass (O3D_ONE_LAUNCH=0: two launches)
   double cert_gap = 0.0625;  // extra search reach for the certificates' slack, in cells (O3D_CERT_GAP)
   int icp_ready = 0;
   int max_iter = 0;

@@ -65,3 +65,17 @@ def test_expand_correspondences_host_helper():
     assert lib.o3d_expand_correspondences(corr.ctypes.data, 0, out.ctypes.data) == 0
     none = np.full(8, -1, np.int32)
     assert lib.o3d_expand_correspondences(none.ctypes.data, 8, out.ctypes.data) == 0
+
+
+def test_adapter_open3d_types_branch_compiles():
+    """The branch of the C++ adapter a maintainer of the reference compiles (O3D_AMD_USE_OPEN3D_TYPES: open3d::geometry::PointCloud
+    and Eigen types instead of the layout-compatible stand-ins) parses and type-checks -- against tests/cpp/compile_stub, a
+    types-only stub (the image has neither Eigen nor the reference's headers installed)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stamp = os.path.join(root, "tests", "cpp", "compile_check")
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    p = subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp"), "compile_check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]

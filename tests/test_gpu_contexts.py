@@ -4,7 +4,7 @@ import pytest
 
 from conftest import make_scene
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cert_policy")]
 
 
 def _reg():

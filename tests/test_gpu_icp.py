@@ -8,7 +8,7 @@ import pytest
 
 from conftest import make_scene, rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cert_policy")]
 
 TOL = 1e-6
 
