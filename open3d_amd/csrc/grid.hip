@@ -529,7 +529,8 @@ static void choose_grid(const double bb[6], int64_t nfinite, double max_dist, bo
     // every target point, and every other query has all 26 neighbour cells inside the table (no bounds checks).
     for (int d = 0; d < 3; d++) c[d] = floor(ext[d] / h) + 1.0 + (d == 0 ? 2.0 : 4.0);
     total = (c[0] + 2.0) * c[1] * c[2];
-    if (total < (double)kMaxDenseCells && total <= budget) {
+    static const bool force_bricks = getenv("O3D_FORCE_BRICKS") != nullptr;  // tuning aid
+    if (total < (double)kMaxDenseCells && total <= budget && !(force_bricks && first && bricks)) {
       gp.nx = (int)c[0]; gp.ny = (int)c[1]; gp.nz = (int)c[2];
       break;
     }

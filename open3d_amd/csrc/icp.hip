@@ -24,6 +24,9 @@
 #ifndef O3D_CENTRE_MIN
 #define O3D_CENTRE_MIN 64
 #endif
+#ifndef O3D_EXPERIMENT_ONE_LOAD
+#define O3D_EXPERIMENT_ONE_LOAD 0
+#endif
 
 namespace {
 
@@ -619,7 +622,12 @@ struct F32State {
 __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_t j, uint32_t e, float qx, float qy, float qz,
                                           int cxp, float hf, F32State &st) {
   const float4 *__restrict__ p = tl + j;
+#if O3D_EXPERIMENT_ONE_LOAD  // timing experiment only (wrong results): what the kernel costs with a quarter of the candidate loads
+  const float4 c0 = p[0];
+  const float4 c[4] = {c0, make_float4(c0.x + 1e18f, c0.y, c0.z, c0.w), make_float4(c0.x, c0.y + 1e18f, c0.z, c0.w), make_float4(c0.x, c0.y, c0.z + 1e18f, c0.w)};
+#else
   const float4 c[4] = {p[0], p[1], p[2], p[3]};
+#endif
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const float dx = qx - (c[u].x + (float)(__float_as_int(c[u].w) - cxp) * hf);
