@@ -740,7 +740,8 @@ int o3d_sort_source(o3d_ctx *ctx, const double *dev_xyz, int64_t n, const double
     O3D_HIP(ctx, hipMalloc((void **)&ctx->pos_sorted, sizeof(uint32_t) * nn));
     O3D_HIP(ctx, hipMalloc((void **)&ctx->lb_sorted, sizeof(float) * nn));
     // k_icp_cert's chunks are rounded up to whole wavefronts: a segment may start (not reach) beyond n
-    O3D_HIP(ctx, hipMalloc((void **)&ctx->work, sizeof(uint32_t) * (nn + 4 * O3D_BLOCK)));
+    // (one list per wavefront of the largest grid, each rounded up to whole blocks of 64: icp.hip, plan_pass)
+    O3D_HIP(ctx, hipMalloc((void **)&ctx->work, sizeof(uint32_t) * (nn + (size_t)O3D_WAVE * (4 * O3D_MAX_GRID + 8))));
     ctx->cap_src = nn;
   }
   if (n <= 0) return O3D_OK;

@@ -24,9 +24,6 @@
 #ifndef O3D_CENTRE_MIN
 #define O3D_CENTRE_MIN 64
 #endif
-#ifndef O3D_EXPERIMENT_ONE_LOAD
-#define O3D_EXPERIMENT_ONE_LOAD 0
-#endif
 
 namespace {
 
@@ -622,12 +619,7 @@ struct F32State {
 __device__ __forceinline__ void scan4_f32(const float4 *__restrict__ tl, uint32_t j, uint32_t e, float qx, float qy, float qz,
                                           int cxp, float hf, F32State &st) {
   const float4 *__restrict__ p = tl + j;
-#if O3D_EXPERIMENT_ONE_LOAD  // timing experiment only (wrong results): what the kernel costs with a quarter of the candidate loads
-  const float4 c0 = p[0];
-  const float4 c[4] = {c0, make_float4(c0.x + 1e18f, c0.y, c0.z, c0.w), make_float4(c0.x, c0.y + 1e18f, c0.z, c0.w), make_float4(c0.x, c0.y, c0.z + 1e18f, c0.w)};
-#else
   const float4 c[4] = {p[0], p[1], p[2], p[3]};
-#endif
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const float dx = qx - (c[u].x + (float)(__float_as_int(c[u].w) - cxp) * hf);
@@ -798,21 +790,41 @@ __device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tg
 // cloud) turns the first launch into a no-op when the bounds cannot hold anyway; the search then runs over everything,
 // as it does in the first pass.
 
-// The wavefront's share of the source: one segment of PassArgs::seg_len positions (a multiple of 64), segment number =
-// chunk * 4 + wavefront, workgroup -> chunk XCD-aware (see k_icp_search).  k_icp_cert and k_icp_search_coop run on the same
-// grid and walk the same segments; the work list and its counters are per segment.
+// The wavefront's share of the source.  The grid is dealt round-robin over the 8 XCDs (workgroups b and b + 8 share one, and an
+// L2): XCD x owns the x-th eighth of the processing order, and its wavefronts sweep that eighth TOGETHER -- trip t of the XCD's
+// w-th wavefront is block t * W + w of 64 consecutive positions (W wavefronts per XCD).  The wavefronts that run at the same
+// time are then neighbours on the Hilbert curve: a candidate line, table row or matched record one of them has fetched is in
+// the XCD's L2 when the next one wants it.  (With one contiguous segment per wavefront the 512 wavefronts of an XCD worked at
+// 512 places far apart; the L2 -- 4 MB -- could hold none of what neighbouring segments share, and a pass that searches
+// everything fetched 2.5 GB for the 1.1 GB it needs.)  k_icp_cert and k_icp_search_coop run on the same grid and walk the same
+// blocks; the work list and its counters are per wavefront: segment number = chunk * 4 + wavefront, PassArgs::seg_len list
+// places each (a multiple of 64, at least what the wavefront's blocks hold).
 struct WaveRange {
   unsigned chunk, seg;
-  int64_t beg, end;
+  int64_t first, stride, end;  // positions first + t * stride + lane, t = 0, 1, ..., while below end
+  int64_t count;               // positions in all
+  int64_t list;                // first place of the wavefront's work list
 };
 __device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, unsigned gdim) {
   WaveRange r;
-  r.chunk = (blockIdx.x & 7u) * (gdim >> 3) + (blockIdx.x >> 3);
+  const unsigned xcd = blockIdx.x & 7u, wg = blockIdx.x >> 3;
+  const unsigned per_xcd = gdim >> 3;  // workgroups per XCD (the launch grids are multiples of 8)
+  r.chunk = xcd * per_xcd + wg;        // partial row of the workgroup
   r.seg = r.chunk * 4u + (threadIdx.x >> 6);
-  r.beg = (int64_t)r.seg * seg_len;
-  r.end = r.beg + seg_len;
-  if (r.end > n_src) r.end = n_src;
-  if (r.beg > r.end) r.beg = r.end;
+  const int64_t blocks = (n_src + O3D_WAVE - 1) / O3D_WAVE;
+  const int64_t eighth = (blocks + 7) / 8;  // blocks per XCD
+  const int64_t w = (int64_t)wg * 4 + (threadIdx.x >> 6), W = (int64_t)per_xcd * 4;
+  int64_t b_end = (int64_t)(xcd + 1) * eighth;
+  if (b_end > blocks) b_end = blocks;
+  r.first = ((int64_t)xcd * eighth + w) * O3D_WAVE;
+  r.stride = W * O3D_WAVE;
+  r.end = b_end * O3D_WAVE < n_src ? b_end * O3D_WAVE : n_src;
+  if (r.first > r.end) r.first = r.end;
+  // (the last block of the cloud may be short)
+  const int64_t span = r.end - r.first;
+  const int64_t full = span > 0 ? (span - 1) / r.stride : 0;  // trips before the last
+  r.count = span > 0 ? full * O3D_WAVE + (span - full * r.stride < O3D_WAVE ? span - full * r.stride : O3D_WAVE) : 0;
+  r.list = (int64_t)r.seg * seg_len;
   return r;
 }
 
@@ -841,7 +853,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
   unsigned long long ncert = 0;
   uint32_t nwork = 0;  // wave-uniform
-  for (int64_t base = wr.beg; base < wr.end; base += O3D_WAVE) {
+  for (int64_t base = wr.first; base < wr.end; base += wr.stride) {
     const int64_t i = base + lane;
     const bool valid = i < wr.end;
     double x = 0, y = 0, z = 0;
@@ -915,7 +927,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
       else a.lb[i] = lbc;
     }
     const unsigned long long need = __ballot(valid && !certified);
-    if (valid && !certified) a.work[wr.beg + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    if (valid && !certified) a.work[wr.list + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
     nwork += (uint32_t)__popcll(need);
     if (a.stats) ncert += __popcll(__ballot(certified));
     push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
@@ -975,7 +987,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   double T[12], w[4];
   load_update(a.st, T, w);
   const WaveRange wr = wave_range(a.n_src, a.seg_len, gdim);
-  const int64_t nq = listed ? (int64_t)a.work_count[wr.seg] : wr.end - wr.beg;  // wave-uniform
+  const int64_t nq = listed ? (int64_t)a.work_count[wr.seg] : wr.count;  // wave-uniform
   const float hf = (float)gp.h;
   const float err = kF32Err * hf * hf;
   const float thrf = (float)a.thr;
@@ -1020,8 +1032,8 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
 
   for (int64_t k0 = 0; k0 < nq; k0 += O3D_WAVE) {  // wave-uniform trip count
     const bool valid = k0 + lane < nq;
-    int64_t i = wr.beg + k0 + lane;
-    if (listed && valid) i = a.work[i];
+    int64_t i = wr.first + (k0 / O3D_WAVE) * wr.stride + lane;
+    if (listed && valid) i = a.work[wr.list + k0 + lane];
     double x = 0, y = 0, z = 0;
     uint32_t pprev = O3D_POS_NONE;
     if (valid) {
@@ -2228,7 +2240,9 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pa.cert_row0 = pl.grows;
   {  // one segment per wavefront, the same for both kernels
     const int64_t nseg = 4 * (int64_t)pl.grows;
-    pa.seg_len = ((ctx->n_src + nseg - 1) / nseg + O3D_WAVE - 1) / O3D_WAVE * O3D_WAVE;
+    // (a wavefront takes every W-th block of 64 of its XCD's eighth, W = nseg / 8: see wave_range)
+    const int64_t blocks = (ctx->n_src + O3D_WAVE - 1) / O3D_WAVE, eighth = (blocks + 7) / 8, W = nseg / 8;
+    pa.seg_len = ((eighth + W - 1) / W) * O3D_WAVE;
     if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
   }
   pa.grid_x = pl.grows;
