@@ -580,7 +580,7 @@ int o3d_build_target_grid(o3d_ctx *ctx, const double *dev_xyz, const double *dev
 
   bool want_tn = false;
   if (n > 0) {
-    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * (size_t)n));
+    O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_sorted, &ctx->cap_tgt, sizeof(double4) * ((size_t)n + 8)));  // (+8: k_estimate_normals_hist reads whole batches)
     // four entries of padding: k_icp_search_f32 reads candidates four at a time without clamping
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_local, &ctx->cap_local, sizeof(float4) * ((size_t)n + 4)));
     O3D_TRY(o3d_reserve(ctx, (void **)&ctx->tgt_index, &ctx->cap_tidx, sizeof(uint32_t) * (size_t)n));

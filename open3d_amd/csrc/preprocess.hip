@@ -696,37 +696,72 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
 // k_estimate_normals makes a wavefront execute an insertion whenever ANY of its lanes has one -- for nearly every candidate
 // -- at 38 % lane utilisation, with more scalar (branch, mask) than vector instructions (profiles/r02_c_*).  Here the
 // k nearest of the candidates inside the radius are found by counting:
-//   walk 1  every candidate inside the radius is counted into one of kHistBins equal slices of [0, r^2) by its distance
-//           (a per-lane histogram of byte counters in LDS);
+//   walk    every candidate inside the radius is counted into one of kHistBins equal slices of [0, r^2) by its distance
+//           (a per-lane histogram of byte counters in LDS) and noted down -- (key, position) -- in the lane's column of a
+//           buffer in global memory;
 //   prefix  the slice b* in which the k-th nearest lies; every candidate of a lower slice is among the k nearest;
-//   walk 2  the candidates are visited again: those of lower slices go straight to their slice's place in the list
+//   place   the lane's notes are read back: those of lower slices go straight to their slice's place in the list
 //           (slices are ordered, so the list is ordered up to the order inside a slice), those of slice b* to a short
-//           boundary list;
+//           boundary list.  (Rounds 1-2 walked the block a second time here and computed every distance twice: 43 % of
+//           the kernel's wave cycles; with the notes the kernel takes 7.0 ms instead of 8.0 at 10 M points.)
 //   finish  the boundary list is sorted by a fixed network and its first k - (number below) entries appended; the order
 //           inside the slices is repaired by odd-even transposition rounds until a round moves nothing (two or three).
 // Keys are the distances rounded to float as in the heap; equal keys are ordered by the exact fp64 distances, then by
 // original index (kl_less) -- the kept set and its order are the exact ones, the cumulants are summed in that order.
-// A lane this does not fit (more than kBoundaryCap candidates in slice b*, more than 254 inside the radius) puts its
-// point on a list that k_estimate_normals works off afterwards.
+// A lane this does not fit (more than kBoundaryCap candidates in slice b*, more than kInsideCap - 1 inside the radius)
+// puts its point on a list that k_estimate_normals works off afterwards.
+//
+// What was measured on the way (round 3, Hybrid(4 s, 30) at 10 M points; profiles/r03_d_*): the wavefront is alone or
+// nearly alone on its SIMD (the lists take 21 KiB of LDS), so the kernel runs at the speed of one wavefront's instruction
+// stream -- VALU busy 26 % of its cycles, 42 % spent in s_waitcnt.  Issuing the next batch's loads before the current batch is
+// worked through: 9.9 -> 7.9 ms.  Sharing a batch between the lanes of one cell through LDS (8 x fewer loads): no gain, so
+// the load path is not the limit even though its data-return unit reads 77 % busy.  Batching the LDS atomics of the
+// placing, batching the transposition's pairs, wave-compacted notes with cooperative placing, deferring the notes'
+// stores: each between 0 and 6 % slower.
 constexpr int kHistBins = 32;
 constexpr int kBoundaryCap = 8;
 constexpr int kHistMaxKnn = 64;
 constexpr int kHistLoads = 8;
+constexpr int kInsideCap = 255;  // candidates inside the radius that a lane can note down; one more and the heap kernel takes the point
+
+// The workgroups are persistent (grid-stride over the wavefront-sized chunks of the cloud): as many as the LDS lets run at
+// once, so that the notes of the walk -- kInsideCap entries per lane -- are a buffer of ~200 MB of which a fifth is touched
+// and re-used chunk after chunk, most of it out of L2 and the Infinity Cache.
+static int64_t hist_grid(size_t lds_bytes) {
+  return (int64_t)O3D_NUM_CU * std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(160 * 1024 / lds_bytes)));
+}
+static size_t hist_inside_bytes(int64_t grid) { return sizeof(uint2) * (size_t)grid * 255 * 64; }
 
 __host__ __device__ constexpr size_t hist_lds_bytes(int knn) {
   return (size_t)kNrmBlock * (8 * (size_t)knn + kHistBins + 8 * kBoundaryCap);
 }
 
-// The nine rows of the 3x3x3 block as one sequence of batches: kHistLoads consecutive candidates of the lane's current row in
-// flight, the row bookkeeping once per batch (walk_block3 does it per candidate, which costs more instructions than the
-// candidate itself; walking row by row in lock step makes every row cost its longest lane: 12.6 ms against 11.5).  The
-// slots past a row's end are padding (`pad` is any valid position, real = false).
-template <typename F>
-__device__ __forceinline__ void walk_rows(const double4 *__restrict__ pts, const uint32_t (&rs)[9], const uint32_t (&re)[9], uint32_t pad,
-                                          F &&visit) {
-  int r = 0;
-  uint32_t j = rs[0], e = re[0];
-  auto next_row = [&]() {  // (static indices only: the bounds stay in registers)
+struct RowBatch {
+  double x[kHistLoads], y[kHistLoads], z[kHistLoads];
+  uint32_t j, e;  // candidate u is position j + u, and real iff j + u < e
+};
+
+__device__ __forceinline__ void batch_load(RowBatch &b, const double4 *__restrict__ pts, uint32_t j, uint32_t e) {
+  const double4 *__restrict__ pp = pts + j;
+#pragma unroll
+  for (int u = 0; u < kHistLoads; u++) {
+    b.x[u] = pp[u].x; b.y[u] = pp[u].y; b.z[u] = pp[u].z;
+  }
+  b.j = j;
+  b.e = e;
+}
+
+// The state of a lane's walk over the nine rows of its block: batches of kHistLoads consecutive candidates of the current
+// row, the row bookkeeping once per batch (walk_block3 does it per candidate, which costs more instructions than the
+// candidate itself; walking row by row in lock step makes every row cost its longest lane: 12.6 ms against 11.5).
+struct RowWalk {
+  int r;
+  uint32_t j, e;
+  __device__ __forceinline__ void start(const uint32_t (&rs)[9], const uint32_t (&re)[9]) {
+    r = 0; j = rs[0]; e = re[0];
+    settle(rs, re);
+  }
+  __device__ __forceinline__ void settle(const uint32_t (&rs)[9], const uint32_t (&re)[9]) {  // (static indices only: the bounds stay in registers)
     while (j >= e && r < 8) {
       r++;
 #pragma unroll
@@ -735,16 +770,36 @@ __device__ __forceinline__ void walk_rows(const double4 *__restrict__ pts, const
         e = r == i ? re[i] : e;
       }
     }
-  };
-  next_row();
-  while (j < e) {
-    double4 tq[kHistLoads];
-#pragma unroll
-    for (int u = 0; u < kHistLoads; u++) tq[u] = pts[j + u < e ? j + u : pad];
-#pragma unroll
-    for (int u = 0; u < kHistLoads; u++) visit(tq[u], j + u, j + u < e);
+  }
+  __device__ __forceinline__ void advance(const uint32_t (&rs)[9], const uint32_t (&re)[9]) {
     j += kHistLoads;
-    next_row();
+    settle(rs, re);
+  }
+  __device__ __forceinline__ bool more() const { return j < e; }
+};
+
+// Every lane loads its own candidates: one address and 2 * kHistLoads loads at immediate offsets per batch; the slots past
+// the row's end read the next cells' points (the array carries kHistLoads entries of padding) and come with real = false.
+// Two batches are kept in registers: the loads of the next one are issued before the current one is worked through, so that
+// a wavefront -- there are fewer than two per SIMD, the lists live in LDS -- does not wait out a cache miss per batch.
+template <typename F>
+__device__ __forceinline__ void walk_rows(const double4 *__restrict__ pts, const uint32_t (&rs)[9], const uint32_t (&re)[9], F &&visit) {
+  RowWalk w;
+  w.start(rs, re);
+  if (!w.more()) return;
+  RowBatch b0, b1;
+  batch_load(b0, pts, w.j, w.e);
+  for (;;) {
+    w.advance(rs, re);
+    const bool more1 = w.more();
+    batch_load(b1, pts, more1 ? w.j : b0.j, more1 ? w.e : 0u);  // (nothing left: a batch of padding at an address known to be valid)
+    visit(b0);
+    if (!more1) break;
+    w.advance(rs, re);
+    const bool more0 = w.more();
+    batch_load(b0, pts, more0 ? w.j : b1.j, more0 ? w.e : 0u);
+    visit(b1);
+    if (!more0) break;
   }
 }
 
@@ -753,10 +808,13 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
                                                                       double thr, double *normals, int has_normals, int by_pos,
                                                                       const double *ref, uint32_t *__restrict__ fb_list,
                                                                       uint32_t *__restrict__ fb_count, int knn_only,
-                                                                      double *__restrict__ cov_out) {
+                                                                      double *__restrict__ cov_out, uint2 *__restrict__ inside) {
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
-  // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary positions
+  // the workgroup's part of `inside`: [kInsideCap][lane] (key, position) of the candidates the walk found inside the radius
+  uint2 *const mine = inside + (size_t)blockIdx.x * kInsideCap * kNrmBlock + lane;
+  // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary
+  // positions
   float *lkey = reinterpret_cast<float *>(smem) + lane;
   uint32_t *lpos = reinterpret_cast<uint32_t *>(smem + sizeof(float) * kNrmBlock * (size_t)knn) + lane;
   uint32_t *hist = reinterpret_cast<uint32_t *>(smem + 8 * (size_t)kNrmBlock * (size_t)knn) + lane;
@@ -764,7 +822,9 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
   float *bkey = reinterpret_cast<float *>(hist + (kHistBins / 4) * kNrmBlock);
   uint32_t *bpos = reinterpret_cast<uint32_t *>(bkey + kBoundaryCap * kNrmBlock);
   const float thrf = (float)thr;
-  const float scale = (float)kHistBins / thrf;
+  // slices of equal width in the key; the factor below 1 keeps key * scale under kHistBins for every key up to thrf, the
+  // rounding of the three float operations included, so the slice number needs no clamp (any monotone slicing will do)
+  const float scale = ((float)kHistBins / thrf) * (1.0f - 1.0f / 1048576.0f);
   KList l;  // only for the exact tie-break of kl_less
   l.pts = pts;
 
@@ -780,22 +840,32 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
     block3_bounds(cell_start, gp, cx, cy, cz, rs, re);
 #pragma unroll
     for (int w = 0; w < kHistBins / 4; w++) hist[w * kNrmBlock] = 0u;
-    // walk 1: count
+    // walk: what is found inside the radius is counted into the slices and noted down.  At most kInsideCap candidates are
+    // counted and noted, so no byte counter overflows; a point with more inside the radius goes to the heap kernel below
+    // (fb), and what it does until then it does on a consistent part of them (counting on while the notes stop would leave
+    // list places unwritten: stale LDS as positions).
     int n_in = 0;
-    walk_rows(pts, rs, re, (uint32_t)p, [&](const double4 &t, uint32_t, bool real) {
-      const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
-      double d2 = ddx * ddx;
-      d2 = d2 + ddy * ddy;
-      d2 = d2 + ddz * ddz;
-      if (real && d2 < thr) {
-        const int bin = min((int)((float)d2 * scale), kHistBins - 1);
-        if (n_in < 255) atomicAdd(&hist[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
-        n_in++;
+    walk_rows(pts, rs, re, [&](const RowBatch &b) {
+#pragma unroll
+      for (int u = 0; u < kHistLoads; u++) {
+        const double ddx = q.x - b.x[u], ddy = q.y - b.y[u], ddz = q.z - b.z[u];
+        double d2 = ddx * ddx;
+        d2 = d2 + ddy * ddy;
+        d2 = d2 + ddz * ddz;
+        if (b.j + u < b.e && d2 < thr) {
+          if (n_in < kInsideCap) {  // (what is counted is what is noted: the slices and the list places stay consistent)
+            const float kf = (float)d2;
+            const int bin = (int)(kf * scale);
+            atomicAdd(&hist[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
+            mine[n_in * kNrmBlock] = make_uint2(__float_as_uint(kf), b.j + u);
+          }
+          n_in++;
+        }
       }
     });
-    // a byte counter may have saturated; KNN search (thr = the cell side squared, what the 3x3x3 block is guaranteed to
-    // cover): with fewer than k points that near, the k-th neighbour lies outside the block
-    bool fb = n_in >= 255 || (knn_only && n_in < knn);
+    // KNN search (thr = the cell side squared, what the 3x3x3 block is guaranteed to cover): with fewer than k points that
+    // near, the k-th neighbour lies outside the block
+    bool fb = n_in >= kInsideCap || (knn_only && n_in < knn);
     const int k_eff = min(knn, n_in);
     // prefix: slice of the k-th nearest, number of candidates below it, first list place of every slice
     int bstar = kHistBins, c_lo = 0;
@@ -815,27 +885,31 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
         offs[w * kNrmBlock] = ow;
       }
     }
-    // walk 2: place
+    // placing: the notes are read back -- a lane's own stores, in order -- and go by their slice either to their place in
+    // the list or to the boundary list
     int nb = 0;
-    if (k_eff > 0) {
-      walk_rows(pts, rs, re, (uint32_t)p, [&](const double4 &t, uint32_t j, bool real) {
-        const double ddx = q.x - t.x, ddy = q.y - t.y, ddz = q.z - t.z;
-        double d2 = ddx * ddx;
-        d2 = d2 + ddy * ddy;
-        d2 = d2 + ddz * ddz;
-        if (real && d2 < thr) {
-          const float kf = (float)d2;
-          const int bin = min((int)(kf * scale), kHistBins - 1);
-          if (bin < bstar) {
-            const uint32_t old = atomicAdd(&offs[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
-            const int dst = (int)((old >> ((bin & 3) * 8)) & 255u);
-            if (dst < knn) { lkey[dst * kNrmBlock] = kf; lpos[dst * kNrmBlock] = j; }
-          } else if (bin == bstar) {
-            if (nb < kBoundaryCap) { bkey[nb * kNrmBlock] = kf; bpos[nb * kNrmBlock] = j; }
-            nb++;
+    {
+      const int n_read = min(n_in, kInsideCap);
+      for (int i0 = 0; i0 < n_read; i0 += kHistLoads) {
+        uint2 en[kHistLoads];
+#pragma unroll
+        for (int u = 0; u < kHistLoads; u++) en[u] = mine[min(i0 + u, kInsideCap - 1) * kNrmBlock];
+#pragma unroll
+        for (int u = 0; u < kHistLoads; u++) {
+          if (i0 + u < n_read) {
+            const float kf = __uint_as_float(en[u].x);
+            const int bin = (int)(kf * scale);
+            if (bin < bstar) {
+              const uint32_t old = atomicAdd(&offs[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
+              const int dst = (int)((old >> ((bin & 3) * 8)) & 255u);
+              if (dst < knn) { lkey[dst * kNrmBlock] = kf; lpos[dst * kNrmBlock] = en[u].y; }
+            } else if (bin == bstar) {
+              if (nb < kBoundaryCap) { bkey[nb * kNrmBlock] = kf; bpos[nb * kNrmBlock] = en[u].y; }
+              nb++;
+            }
           }
         }
-      });
+      }
     }
     fb = fb || nb > kBoundaryCap;
     // boundary slice: sort (fixed 19-comparator network for 8), append the k_eff - c_lo nearest
@@ -876,7 +950,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
             if (i + 1 < c_lo) {
               const float ka = lkey[i * kNrmBlock], kb = lkey[(i + 1) * kNrmBlock];
               if (kb <= ka) {
-                const uint32_t pa = lpos[i * kNrmBlock], pb = lpos[(i + 1) * kNrmBlock];
+                uint32_t pa = lpos[i * kNrmBlock], pb = lpos[(i + 1) * kNrmBlock];
                 if (kb < ka || kl_less(l, kb, pb, ka, pa)) {
                   lkey[i * kNrmBlock] = kb; lkey[(i + 1) * kNrmBlock] = ka;
                   lpos[i * kNrmBlock] = pb; lpos[(i + 1) * kNrmBlock] = pa;
@@ -896,7 +970,10 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
     for (int i0 = 0; i0 < k; i0 += kHistLoads) {  // ComputeNormal :222-233, in the neighbour order FLANN returns
       double4 tq[kHistLoads];
 #pragma unroll
-      for (int u = 0; u < kHistLoads; u++) tq[u] = pts[lpos[min(i0 + u, k - 1) * kNrmBlock]];
+      for (int u = 0; u < kHistLoads; u++) {
+        uint32_t at = lpos[min(i0 + u, k - 1) * kNrmBlock];
+        tq[u] = pts[at];
+      }
 #pragma unroll
       for (int u = 0; u < kHistLoads; u++) {
         if (i0 + u < k) {
@@ -1462,9 +1539,9 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
   const size_t bytes = sizeof(double) * 3 * (size_t)n;
   const double *d_xyz = xyz;
   double *d_nrm = normals;
-  void *sx = nullptr, *sn = nullptr, *sp = nullptr, *sf = nullptr, *sc = nullptr;
+  void *sx = nullptr, *sn = nullptr, *sp = nullptr, *sf = nullptr, *sc = nullptr, *si = nullptr;
   auto cleanup = [&]() {
-    for (void *b : {sx, sn, sp, sf, sc})
+    for (void *b : {sx, sn, sp, sf, sc, si})
       if (b) o3d_tmp_free(ctx, b);
   };
   auto run = [&]() -> int {
@@ -1532,7 +1609,7 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
                            ctx->cell_start, ctx->gp, 1, 0.0, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
-      } else if (knn_hist) {
+      } else if (knn_hist && ctx->gp.h > 1e-15) {  // (the slice number is unclamped: keep key * scale finite)
         O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
         uint32_t *fb_list = (uint32_t *)sf + 64, *fb_count = (uint32_t *)sf;
         O3D_HIP(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), ctx->stream));
@@ -1540,8 +1617,10 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         const double thr_knn = (double)(float)(reach * reach);
         const size_t hlds = hist_lds_bytes(kk);
         O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
-        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr_knn, d_out, has_normals, by_pos, ref, fb_list, fb_count, 1, d_cov);
+        const int64_t gh = std::min<int64_t>(g, hist_grid(hlds));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &si, hist_inside_bytes(gh)));
+        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)gh), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr_knn, d_out, has_normals, by_pos, ref, fb_list, fb_count, 1, d_cov, (uint2 *)si);
         O3D_TRY(allow_lds(ctx, k_estimate_normals<0>, lds));
         hipLaunchKernelGGL(k_estimate_normals<0>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 4)), dim3(kNrmBlock), lds, ctx->stream,
                            ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,
@@ -1554,15 +1633,17 @@ static int estimate_normals_run(o3d_ctx *ctx, const double *xyz, int64_t n, int 
         O3D_TRY(allow_lds(ctx, k_estimate_normals<1>, lds));
         hipLaunchKernelGGL(k_estimate_normals<1>, dim3((int)g), dim3(kNrmBlock), lds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
                            ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, nullptr, nullptr, d_cov);
-      } else if (kk <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP")) {
+      } else if (kk <= kHistMaxKnn && !getenv("O3D_NORMALS_HEAP") && radius > 1e-15) {
         // hybrid: selection by counting (k_estimate_normals_hist); what does not fit it is left on a list for the heap kernel
         O3D_HIP(ctx, o3d_tmp_alloc(ctx, &sf, sizeof(uint32_t) * ((size_t)(p_hi - p_lo) + 64)));
         uint32_t *fb_list = (uint32_t *)sf + 64, *fb_count = (uint32_t *)sf;
         O3D_HIP(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), ctx->stream));
         const size_t hlds = hist_lds_bytes(kk);
         O3D_TRY(allow_lds(ctx, k_estimate_normals_hist, hlds));
-        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)g), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
-                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count, 0, d_cov);
+        const int64_t gh = std::min<int64_t>(g, hist_grid(hlds));
+        O3D_HIP(ctx, o3d_tmp_alloc(ctx, &si, hist_inside_bytes(gh)));
+        hipLaunchKernelGGL(k_estimate_normals_hist, dim3((int)gh), dim3(kNrmBlock), hlds, ctx->stream, ctx->tgt_sorted, p_lo, p_hi,
+                           ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref, fb_list, fb_count, 0, d_cov, (uint2 *)si);
         O3D_TRY(allow_lds(ctx, k_estimate_normals<2>, lds));
         hipLaunchKernelGGL(k_estimate_normals<2>, dim3((int)std::min<int64_t>(g, O3D_NUM_CU * 2)), dim3(kNrmBlock), lds, ctx->stream,
                            ctx->tgt_sorted, p_lo, p_hi, ctx->cell_start, ctx->gp, kk, thr, d_out, has_normals, by_pos, ref,

@@ -16,6 +16,7 @@ from open3d_amd import _lib, synthetic  # noqa: E402
 
 ctx = _lib.Context(0)
 dev = torch.device("cuda", 0)
+only = os.environ.get("NRM_ONLY")  # e.g. hybrid_4s_30: one search only (for counter passes)
 for n in [int(a) for a in sys.argv[1:]] or [1_000_000, 10_000_000]:
     sc = synthetic.make_pair(n, n, cfg_id=3, L=synthetic.extent_for(n))
     s = sc["spacing"]
@@ -23,6 +24,8 @@ for n in [int(a) for a in sys.argv[1:]] or [1_000_000, 10_000_000]:
     d_nrm = torch.empty_like(d_xyz)
     row = {"points": n, "heap_kernel_forced": bool(os.environ.get("O3D_NORMALS_HEAP"))}
     for name, st, knn, radius in (("knn30", 0, 30, 0.0), ("hybrid_4s_30", 2, 30, 4 * s), ("knn12", 0, 12, 0.0)):
+        if only and name != only:
+            continue
         best = 1e9
         for rep in range(4):
             torch.cuda.synchronize()
