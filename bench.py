@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--estimation", default="p2plane", choices=["p2plane", "p2p"])
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--cpu-sample-1t", type=int, default=500_000, help="source points of the one-thread CPU baseline leg")
+    ap.add_argument("--cpu-sample-1t", type=int, default=2_000_000, help="source points of the one-thread CPU baseline leg")
     ap.add_argument("--no-hard-scene", dest="hard_scene", action="store_false", help="skip the hard-scene leg (config.hard_scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks", type=int, default=5,
@@ -368,14 +368,19 @@ def main():
                                      if steady and steady.get("pass_kernel_ms") else None,
             },
         }
-        # HBM traffic per k_icp_pass launch from the PMC passes of this same command (scripts/prof_pmc.sh; counters cannot be
+        # HBM traffic per k_icp_pass launch from the PMC passes of this same command (scripts/prof_r03.sh; counters cannot be
         # read from inside the process): 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads; applied to all
-        # reads, so an upper bound) + WRITE_SIZE.  Only quoted for the workload it was collected on.
+        # reads, so an upper bound) + WRITE_SIZE, averaged like `achieved` over the K launches of a registration -- one that
+        # searches the whole cloud, K - 1 that certify.  Only quoted for the workload it was collected on.
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and n == 10_000_000 and args.estimation == "p2plane" and args.search == "f32" and os.path.exists(tpath):
             with open(tpath) as f:
                 tr = json.load(f)
-            out["roofline"]["traffic"] = (2.0 * tr["fetch_size_kb"] + tr["write_size_kb"]) * 1024.0
+            per = {k: (2.0 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024.0 for k, v in tr["k_icp_pass"].items()}
+            out["roofline"]["traffic"] = (per["search_all"] + (args.steps - 1) * per["steady"]) / args.steps
+            out["roofline"]["traffic_per_kind"] = per
+            out["roofline"]["search_pass"]["traffic"] = (2.0 * tr["k_icp_search_coop"]["fetch_size_kb"]
+                                                         + tr["k_icp_search_coop"]["write_size_kb"]) * 1024.0
             out["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             n_sample = min(args.cpu_sample, n)

@@ -853,43 +853,77 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   v4f64 S = {0.0, 0.0, 0.0, 0.0};
   unsigned long long ncert = 0;
   uint32_t nwork = 0;  // wave-uniform
+  // The loop is software-pipelined over three trips: while trip t is worked through, the matched records of trip t + 1 are
+  // being gathered (their positions arrived a trip ago) and the points, positions and bounds of trip t + 2 are being read.
+  // A wavefront otherwise waits out two dependent trips to memory per trip (point -> record) with only the other three
+  // wavefronts of its SIMD to cover them.  Every load is issued unconditionally, at a clamped index where the lane has
+  // nothing to read: a load inside a branch makes the wait for an OLDER load a wait for everything in flight (one counter,
+  // and the compiler cannot know how many younger loads were issued).
+  struct StageA {  // what is streamed: the point, the position of its previous match, its bound
+    double x, y, z;
+    uint32_t pprev;
+    float lbv;
+  };
+  struct StageB {  // what is gathered: the matched record
+    double4 p, tc;
+    double n0, n1, n2, is;
+  };
+  const int64_t i_last = wr.end - 1;  // (only used when the wavefront has a trip: wr.first < wr.end)
+  auto load_a = [&](int64_t base) {
+    StageA s;
+    int64_t i = base + lane;
+    if (i > i_last) i = i_last;
+    if constexpr (stream) {
+      s.pprev = __builtin_nontemporal_load(&a.pos[i]);
+      s.lbv = __builtin_nontemporal_load(&a.lb[i]);
+      s.x = __builtin_nontemporal_load(&a.src[3 * i]); s.y = __builtin_nontemporal_load(&a.src[3 * i + 1]); s.z = __builtin_nontemporal_load(&a.src[3 * i + 2]);
+    } else {
+      s.pprev = a.pos[i];
+      s.lbv = a.lb[i];
+      s.x = a.src[3 * i]; s.y = a.src[3 * i + 1]; s.z = a.src[3 * i + 2];
+    }
+    return s;
+  };
+  auto load_b = [&](const StageA &s, int64_t base) {
+    StageB r;
+    int64_t i = base + lane;
+    if (i > i_last) i = i_last;
+    const size_t at = s.pprev != O3D_POS_NONE ? (size_t)s.pprev : 0;  // (no previous match: record 0, not used)
+    r.tc = make_double4(0.0, 0.0, 0.0, 0.0);
+    r.n0 = r.n1 = r.n2 = r.is = 0.0;
+    if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one 48-byte record instead of two gathers of 32 and 24 bytes
+      const double2 r0 = a.tn[3 * at], r1 = a.tn[3 * at + 1], r2 = a.tn[3 * at + 2];
+      r.p = make_double4(r0.x, r0.y, r1.x, 0.0);  // (the index in p.w is not needed here: a certified entry is not rewritten)
+      r.n0 = r1.y; r.n1 = r2.x; r.n2 = r2.y;
+    } else {
+      r.p = a.tgt[at];
+      if (EST != O3D_EST_POINT_TO_POINT) {
+        r.n0 = a.nrm[3 * at]; r.n1 = a.nrm[3 * at + 1]; r.n2 = a.nrm[3 * at + 2];
+      }
+    }
+    if (EST == O3D_EST_COLORED_ICP) { r.tc = a.tcol[at]; r.is = a.sint[i]; }
+    return r;
+  };
+  StageA a0, a1, a2;
+  StageB r0, r1;
+  if (wr.first < wr.end) {
+    a0 = load_a(wr.first);
+    a1 = load_a(wr.first + wr.stride);
+    r0 = load_b(a0, wr.first);
+  }
   for (int64_t base = wr.first; base < wr.end; base += wr.stride) {
+    r1 = load_b(a1, base + wr.stride);
+    a2 = load_a(base + 2 * wr.stride);
     const int64_t i = base + lane;
     const bool valid = i < wr.end;
-    double x = 0, y = 0, z = 0;
-    uint32_t pprev = O3D_POS_NONE;
-    float lbv = 0.f, moved = 0.f;
-    // STREAM: the point, its match position and its bound are read and written with streaming (non-temporal) accesses, which
-    // leave the caches to the target records: 0.234 -> 0.229 ms at 10 M points point-to-plane; point-to-point, where a good
-    // part of the cloud goes on to the search in every pass, 0.209 -> 0.204 ms and the search after it 0.148 -> 0.132 ms
-    // (A/B on one box, O3D_STREAM=0/1).
-    if (valid) {
-      if constexpr (stream) {
-        pprev = __builtin_nontemporal_load(&a.pos[i]);
-        lbv = __builtin_nontemporal_load(&a.lb[i]);
-        x = __builtin_nontemporal_load(&a.src[3 * i]); y = __builtin_nontemporal_load(&a.src[3 * i + 1]); z = __builtin_nontemporal_load(&a.src[3 * i + 2]);
-      } else {
-        pprev = a.pos[i];
-        lbv = a.lb[i];
-        x = a.src[3 * i]; y = a.src[3 * i + 1]; z = a.src[3 * i + 2];
-      }
-    }
+    double x = a0.x, y = a0.y, z = a0.z;
+    const uint32_t pprev = valid ? a0.pprev : O3D_POS_NONE;
+    const float lbv = valid ? a0.lbv : 0.f;
+    float moved = 0.f;
     const bool has_prev = valid && pprev != O3D_POS_NONE;
-    double4 p = make_double4(0.0, 0.0, 0.0, 0.0), tc = make_double4(0.0, 0.0, 0.0, 0.0);
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0, is = 0.0;
-    if (has_prev) {
-      if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one 48-byte record instead of two gathers of 32 and 24 bytes
-        const double2 r0 = a.tn[3 * (size_t)pprev], r1 = a.tn[3 * (size_t)pprev + 1], r2 = a.tn[3 * (size_t)pprev + 2];
-        p = make_double4(r0.x, r0.y, r1.x, 0.0);  // (the index in p.w is not needed here: a certified entry is not rewritten)
-        n0 = r1.y; n1 = r2.x; n2 = r2.y;
-      } else {
-        p = a.tgt[pprev];
-        if (EST != O3D_EST_POINT_TO_POINT) {
-          n0 = a.nrm[3 * (size_t)pprev]; n1 = a.nrm[3 * (size_t)pprev + 1]; n2 = a.nrm[3 * (size_t)pprev + 2];
-        }
-      }
-      if (EST == O3D_EST_COLORED_ICP) { tc = a.tcol[pprev]; is = a.sint[i]; }
-    }
+    const double4 p = r0.p, tc = r0.tc;
+    const double n0 = r0.n0, n1 = r0.n1, n2 = r0.n2, is = r0.is;
+    a0 = a1; a1 = a2; r0 = r1;
     if (valid && apply) {
       const double xo = x, yo = y, zo = z;
       apply_update(T, w, x, y, z);
