@@ -273,7 +273,10 @@ O3D_API int o3d_voxel_down_sample(o3d_ctx *ctx, const double *xyz, const double 
                           int32_t *out_voxel_index, int64_t *out_m);
 
 /* PointCloud::EstimateNormals, geometry/EstimateNormals.cpp:320-351 with ComputeNormal :215-252 and FastEigen3x3
- * :130-213 (fast_normal_computation = true, the reference default).  normals is in/out when has_normals != 0. */
+ * :130-213 (fast_normal_computation = true, the reference default).  normals is in/out when has_normals != 0.
+ * Limit: KNN and hybrid searches keep their k nearest in per-lane lists in LDS (8 bytes per entry and lane), so knn / max_nn
+ * may be at most 256; a larger value returns O3D_ERR_UNSUPPORTED (the reference accepts any).  Radius search has no such
+ * limit.  The same limit holds for o3d_compute_fpfh_feature and the colour gradients of o3d_registration_colored_icp. */
 O3D_API int o3d_estimate_normals(o3d_ctx *ctx, const double *xyz, int64_t n, int search_type, int knn, double radius, int mem,
                          double *normals, int has_normals);
 
