@@ -463,7 +463,7 @@ void o3d_ctx_destroy(o3d_ctx *c) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->tgt_local, ctx->tgt_sorted, ctx->nrm_sorted, ctx->cell_start, ctx->src_sorted, ctx->src_perm, ctx->corr_sorted,
                   ctx->corr_out,   ctx->pos_sorted, ctx->lb_sorted, ctx->work, ctx->work_count, ctx->state,      ctx->partials,   ctx->sums,       ctx->log,
-                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_gang, ctx->tgt_index};
+                  ctx->counters,   ctx->gsums,      ctx->brick_dir,  ctx->tn_sorted,  ctx->d_gang, ctx->tgt_index, ctx->tail_check_buf};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (int i = 0; i < 8; i++)
@@ -641,6 +641,8 @@ static int icp_setup_impl(o3d_ctx *ctx, const double *src_xyz, int64_t n_src, co
     ctx->use_stream = e ? (atoi(e) ? 1 : 0) : 1;
     e = getenv("O3D_ONE_LAUNCH");
     ctx->use_one_launch = (e && atoi(e) == 0) ? 0 : 1;
+    e = getenv("O3D_TAIL_CHECK");
+    ctx->tail_check = e ? atoi(e) : 0;  // (2: one line on stderr per check)
   }
   if (const char *e = getenv("O3D_CERT_GAP")) {
     const double v = atof(e);

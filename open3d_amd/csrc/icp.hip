@@ -16,6 +16,7 @@
 // Bit-exactness of the correspondence search: d2 = ((dx*dx)+dy*dy)+dz*dz with separate IEEE multiplies and adds (this
 // file is compiled with -ffp-contract=off), accept iff d2 < (double)(float)(r*r), argmin over (d2, target index).
 #include <math.h>
+#include <string.h>
 
 #include <mutex>
 
@@ -252,6 +253,29 @@ __device__ __forceinline__ void accumulate_colored(double (&acc)[30], double x, 
   acc[O3D_SUM_NC] += 1.0;
 }
 
+// Device-scope accesses: written through to / read from where every XCD sees them (see pass_tail).
+__device__ __forceinline__ double load_device_coherent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_device_coherent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// THE way to write an entry of a partial row (o3d_ctx::partials, PassArgs::partials).  INVARIANT: every store to a partial
+// row, a group row (gsums) or a ticket, and every load of one by pass_tail, is a device-scope access.  pass_tail reads the
+// rows inside the kernel that wrote them, from whichever XCD its last workgroup runs on; the only ordering it has is
+// relaxed agent-scope atomics on the tickets, a workgroup-scope release and s_waitcnt -- no device-wide fence (28 -> 55 us
+// per iteration at 100 k points when tried).  ONE plain store to a row leaves the value in the writer's XCD's L2 and the
+// tail adds what memory held before: the previous registration's row, silently (this happened with the zero row of a
+// certificate half that stands aside).  Rows that only a LATER kernel reads need nothing of this, but go through here as
+// well, so that a writer that moves into a kernel with a tail cannot bring the bug with it.  O3D_TAIL_CHECK=1
+// (o3d_launch_pass) adds every pass's rows once more with k_finalize_plain and compares bit for bit.
+__device__ __forceinline__ void store_partial_row(double *partials, size_t row, int k, double v) {
+  store_device_coherent(partials + row * O3D_NSUMS + k, v);
+}
+
 // Wavefront shuffle reduction, then a fixed-order LDS combine across the four waves -> one partial row per chunk.
 __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*red)[O3D_NSUMS], double *__restrict__ partials,
                                                    unsigned chunk) {
@@ -265,7 +289,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[30], double (*r
   if (threadIdx.x < O3D_NSUMS) {
     double v = 0.0;
     if (threadIdx.x < 30) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    partials[(size_t)chunk * O3D_NSUMS + threadIdx.x] = v;
+    store_partial_row(partials, chunk, (int)threadIdx.x, v);
   }
 }
 
@@ -328,16 +352,6 @@ struct PassArgs {
 __device__ __forceinline__ double uniform_f64(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
-}
-
-// Device-scope accesses: written through to / read from where every XCD sees them (see pass_tail).
-__device__ __forceinline__ double load_device_coherent(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void store_device_coherent(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Defined behind the estimate's algebra below.  Every thread of the workgroup calls it once the workgroup's partial row
@@ -527,7 +541,7 @@ __device__ __forceinline__ void mfma_reduce_store(const v4f64 &S, double (*red)[
         for (int d = 0; d < 3; d++) v += ((red[0][d][d] + red[1][d][d]) + red[2][d][d]) + red[3][d][d];
       }
     }
-    store_device_coherent(partials + (size_t)chunk * O3D_NSUMS + k, v);  // pass_tail may read it from another XCD
+    store_partial_row(partials, chunk, k, v);  // pass_tail may read it from another XCD
   }
 }
 
@@ -840,7 +854,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   if (a.st->skip_cert) {  // the pending update moves the cloud farther than any bound reaches: everything is searched
     // (a device-scope store like every other partial row: in the one-launch form of the pass the row is read by pass_tail
     // in the same kernel, possibly from another XCD, which would find last registration's row behind a plain store)
-    if (tid < O3D_NSUMS) store_device_coherent(a.partials + ((size_t)a.cert_row0 + wr.chunk) * O3D_NSUMS + tid, 0.0);
+    if (tid < O3D_NSUMS) store_partial_row(a.partials, (size_t)a.cert_row0 + wr.chunk, tid, 0.0);
     return;
   }
   VBuf &vb = reinterpret_cast<VBuf *>(lds_raw)[tid >> 6];
@@ -2291,7 +2305,34 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   return pl;
 }
 
+// O3D_TAIL_CHECK=1: what pass_tail added inside the pass's kernel against the separate-launch reduction over the same partial
+// rows, bit for bit (the invariant at store_partial_row: a row written with a plain store shows up here as a difference).
+// `was_done`: the loop had ended before this pass, whose kernels then returned at once.  Synchronises; debugging only.
+static int o3d_tail_check_before(o3d_ctx *ctx, hipStream_t stream, int *was_done) {
+  IcpState hs;
+  O3D_HIP(ctx, hipMemcpyAsync(&hs, ctx->state, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+  O3D_HIP(ctx, hipStreamSynchronize(stream));
+  *was_done = hs.done;
+  return O3D_OK;
+}
+static int o3d_tail_check_after(o3d_ctx *ctx, hipStream_t stream, int nparts, const double *dev_sums, const char *what) {
+  if (!ctx->tail_check_buf) O3D_HIP(ctx, hipMalloc((void **)&ctx->tail_check_buf, sizeof(double) * O3D_NSUMS));
+  hipLaunchKernelGGL(k_finalize_plain, dim3(1), dim3(O3D_FIN_THREADS), 0, stream, (const double *)ctx->partials, nparts, ctx->tail_check_buf);
+  double h[2 * O3D_NSUMS];
+  O3D_HIP(ctx, hipMemcpyAsync(h, ctx->tail_check_buf, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, stream));
+  O3D_HIP(ctx, hipMemcpyAsync(h + O3D_NSUMS, dev_sums, sizeof(double) * O3D_NSUMS, hipMemcpyDeviceToHost, stream));
+  O3D_HIP(ctx, hipStreamSynchronize(stream));
+  for (int k = 0; k < O3D_NSUMS; k++)
+    if (memcmp(&h[k], &h[O3D_NSUMS + k], sizeof(double)) != 0)
+      return o3d_fail(ctx, O3D_ERR_STATE, "O3D_TAIL_CHECK: %s: sum %d of the pass is %a in the kernel's own tail and %a over the same %d partial rows "
+                      "added by a separate launch", what, k, h[O3D_NSUMS + k], h[k], nparts);
+  if (ctx->tail_check > 1) fprintf(stderr, "O3D_TAIL_CHECK: %s: %d partial rows, n = %.0f: equal\n", what, nparts, h[O3D_SUM_NC]);
+  return O3D_OK;
+}
+
 int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
+  int check_done = 0;
+  if (ctx->tail_check && ctx->use_tail) O3D_TRY(o3d_tail_check_before(ctx, ctx->stream, &check_done));
   const bool prof = ctx->prof_on && ctx->prof_n < 340;
   if (prof) {  // three events per pass: before the search kernel, after it, after the accumulation kernel (alternative path)
     for (int k = 0; k < 3; k++)
@@ -2357,6 +2398,7 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
                        dev_sums_out);
 #undef O3D_LAUNCH_EST
   O3D_HIP(ctx, hipGetLastError());
+  if (ctx->tail_check && pl.tail && !check_done) O3D_TRY(o3d_tail_check_after(ctx, ctx->stream, nparts, dev_sums_out, "pass"));
   return O3D_OK;
 }
 
@@ -2402,6 +2444,20 @@ int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool uploa
   const PassLaunch *d = reinterpret_cast<const PassLaunch *>(lead->d_gang) + (first ? 0 : O3D_GANG_MAX);
   const dim3 grid((unsigned)lead->gang_grid, (unsigned)n), block(O3D_BLOCK);
   hipStream_t st = lead->stream;
+  int check_done[O3D_GANG_MAX];
+  const bool check = slots[0]->tail_check != 0;  // (gang-eligible slots end their passes in the kernel: o3d_gang_eligible)
+  if (check)
+    for (int k = 0; k < n; k++) O3D_TRY(o3d_tail_check_before(slots[k], st, &check_done[k]));
+  auto checked = [&]() -> int {  // O3D_TAIL_CHECK=1: every slot's rows once more
+    if (!check) return O3D_OK;
+    for (int k = 0; k < n; k++) {
+      if (check_done[k]) continue;
+      const PassPlan pk = plan_pass(slots[k], slots[k]->sums, 1, !first);
+      const int stt = o3d_tail_check_after(slots[k], st, pk.nparts, slots[k]->sums, "pass of a gang");
+      if (stt != O3D_OK) return o3d_fail(lead, stt, "%s (slot %d of %d)", o3d_last_error(slots[k]), k, n);
+    }
+    return O3D_OK;
+  };
   if (!first && lead->gang_cert && lead->gang_one_launch) {
     if (est == O3D_EST_POINT_TO_PLANE && lead->gang_tn) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_PLANE, true>), grid, block, 0, st, d);
     else if (est == O3D_EST_POINT_TO_PLANE) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_PLANE, false>), grid, block, 0, st, d);
@@ -2409,7 +2465,7 @@ int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool uploa
     else if (est == O3D_EST_COLORED_ICP) hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_COLORED_ICP, false>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((k_icp_pass_batch<O3D_EST_POINT_TO_POINT, false>), grid, block, 0, st, d);
     O3D_HIP(lead, hipGetLastError());
-    return O3D_OK;
+    return checked();
   }
   if (!first && lead->gang_cert) {
     if (lead->gang_stream) {
@@ -2426,7 +2482,7 @@ int o3d_launch_pass_gang(o3d_ctx *lead, o3d_ctx *const *slots, int n, bool uploa
   else if (est == O3D_EST_COLORED_ICP) hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_COLORED_ICP, false>), grid, block, 0, st, d);
   else hipLaunchKernelGGL((k_icp_search_coop_batch<O3D_EST_POINT_TO_POINT, false>), grid, block, 0, st, d);
   O3D_HIP(lead, hipGetLastError());
-  return O3D_OK;
+  return checked();
 }
 
 // Coloured ICP: per sorted target point {intensity, colour gradient}, per processing position the source intensity

@@ -162,6 +162,8 @@ struct o3d_ctx {
   int use_seed = 1;     // k_icp_search_coop: previous match as the first pruning bound (O3D_NO_SEED=1 turns it off)
   int use_bricks = 1;   // sparse scenes get the bricked cell table (O3D_NO_BRICKS=1: coarser cells in a dense table instead)
   int use_tail = 1;     // the search kernel's last workgroups end the pass (O3D_NO_TAIL=1: separate finalize / solve launch)
+  int tail_check = 0;   // O3D_TAIL_CHECK=1 (debugging aid): every pass's partial rows are added once more by k_finalize_plain and compared
+  double *tail_check_buf = nullptr;  // 32 doubles
   int use_cert = 1;     // k_icp_search_coop: certified previous matches skip the search (O3D_NO_CERT=1 turns it off)
   int use_stream = 1;   // certificate half with streaming loads and stores (O3D_STREAM=0: ordinary ones; read per set-up)
   int use_one_launch = 1;  // certificates and search of a pass in one launch, k_icp_pass (O3D_ONE_LAUNCH=0: two launches)

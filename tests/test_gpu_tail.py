@@ -178,3 +178,58 @@ np.save(sys.argv[1], np.concatenate(out))
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=90)
             got.append(np.load(path))
     assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
+
+
+@pytest.mark.gpu
+def test_tail_check_switch_single_and_gang(ctx, oracle):
+    """O3D_TAIL_CHECK=1 (ADVICE, round 2): after every pass that ends inside its kernel the partial rows are added once
+    more by the separate-launch reduction and compared bit for bit with what pass_tail wrote -- the run-time check of the
+    invariant documented at store_partial_row (a partial row written with a plain store would surface here as an
+    O3D_ERR_STATE).  Repeated registrations on ONE context for point-to-point, point-to-plane and coloured ICP with
+    certificates on (later registrations begin with a certificate half that stands aside and must overwrite the previous
+    registration's rows), and the lock-step gang path of the batch entry point; the results must equal the unchecked runs."""
+    import test_gpu_companions as comp
+    from open3d_amd import geometry, synthetic
+    from open3d_amd.pipelines import registration as reg
+    keys = ("O3D_TAIL_CHECK", "O3D_CERT", "O3D_NO_CERT")
+    old = {k: os.environ.get(k) for k in keys}
+
+    def run_all():
+        out = []
+        n = 30000
+        sc = synthetic.make_pair(n, n, cfg_id=0, L=6.0)
+        s = sc["spacing"]
+        nrm = synthetic.surface_normals(sc["target"][:, 0], sc["target"][:, 1])
+        src, tgt = geometry.PointCloud(sc["source"]), geometry.PointCloud(sc["target"], normals=nrm)
+        for est, r in ((reg.TransformationEstimationPointToPlane(), 2 * s), (reg.TransformationEstimationPointToPoint(False), 3 * s)):
+            for k in (3, 1, 4, 3):
+                got = reg.RegistrationICP(src, tgt, r, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, k), ctx=ctx)
+                out.append((got.transformation_.copy(), got.fitness_, got.inlier_rmse_))
+        csc = comp._colored_scene(20000, 20400, cfg_id=77)
+        cn = oracle.estimate_normals(csc["target"], oracle.HYBRID, 30, 4 * csc["spacing"])
+        cs = geometry.PointCloud(csc["source"], colors=csc["source_colors"])
+        ct = geometry.PointCloud(csc["target"], normals=cn, colors=csc["target_colors"])
+        for k in (4, 2, 4):
+            got = reg.RegistrationColoredICP(cs, ct, 2.5 * csc["spacing"], np.eye(4), reg.ICPConvergenceCriteria(0.0, 0.0, k), ctx=ctx)
+            out.append((got.transformation_.copy(), got.fitness_, got.inlier_rmse_))
+        many = reg.RegistrationICPBatch([src] * 5, [tgt] * 5, 2 * s, None, reg.TransformationEstimationPointToPlane(),
+                                        reg.ICPConvergenceCriteria(0.0, 0.0, 6), n_workers=1, ctx=ctx)
+        out += [(m.transformation_.copy(), m.fitness_, m.inlier_rmse_) for m in many]
+        return out
+
+    try:
+        os.environ.pop("O3D_NO_CERT", None)
+        os.environ["O3D_CERT"] = "1"
+        os.environ.pop("O3D_TAIL_CHECK", None)
+        plain = run_all()
+        os.environ["O3D_TAIL_CHECK"] = "1"
+        checked = run_all()  # (raises O3DError with the first differing sum if the tail and the separate launch disagree)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert len(plain) == len(checked)
+    for (Ta, fa, ra), (Tb, fb, rb) in zip(plain, checked):
+        assert np.array_equal(Ta, Tb) and fa == fb and ra == rb
