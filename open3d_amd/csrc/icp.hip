@@ -22,6 +22,16 @@
 
 #include "o3d_internal.h"
 
+#ifndef O3D_SRCH_PROF
+#define O3D_SRCH_PROF 0
+#endif
+#if O3D_SRCH_PROF  // profile build only (scripts/search_phases.sh): wave cycles per phase of a search trip
+__device__ unsigned long long g_srch_prof[8];
+#define SRCH_T(i) { const long long t_now = clock64(); if (lane == 0) atomicAdd(&g_srch_prof[i], (unsigned long long)(t_now - t_prev)); t_prev = clock64(); }
+#else
+#define SRCH_T(i)
+#endif
+
 #ifndef O3D_CENTRE_MIN
 #define O3D_CENTRE_MIN 64
 #endif
@@ -1079,6 +1089,9 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   };
 
   for (int64_t k0 = 0; k0 < nq; k0 += O3D_WAVE) {  // wave-uniform trip count
+#if O3D_SRCH_PROF
+    long long t_prev = clock64();
+#endif
     const bool valid = k0 + lane < nq;
     int64_t i = wr.first + (k0 / O3D_WAVE) * wr.stride + lane;
     if (listed && valid) i = a.work[wr.list + k0 + lane];
@@ -1115,7 +1128,9 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
     const bool has_seed = inside && pprev != O3D_POS_NONE;
     double4 ps = make_double4(0.0, 0.0, 0.0, 0.0);
     if (has_seed) ps = a.tgt[pprev];
+    SRCH_T(0)
     if (k0 != 0) consume();  // the previous trip's matches, behind this trip's source, table and seed loads
+    SRCH_T(1)
     bool too_long = s3 - s0 >= kRunMaxLen;
     float seedb = INFINITY;
     if (has_seed) {
@@ -1137,6 +1152,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
     // Dense cells (a search radius of several point spacings): where the wavefront's own cells hold a round of work beyond
     // their first chunks, those are scanned cooperatively before the listing, so that the bound the neighbouring cells are
     // pruned with is the whole cell's; otherwise they ride along with the neighbours' runs.
+    SRCH_T(2)
     const uint32_t rem = (own && s2 - s1 > 4u) ? (s2 - s1 - 1u) >> 2 : 0u;
     const bool centre_phase = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(rem), O3D_WAVE - 1) >= kCentrePhaseMin;
     unsigned trips = 0;
@@ -1198,7 +1214,9 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
       if (too_long) tot = 0;
     }
     wave_lds_sync();
+    SRCH_T(3)
     trips += coop_phase(wl, lane, 0, tot, tl, hf);
+    SRCH_T(4)
     uint32_t bpos = O3D_POS_NONE;
     float lbn = (valid && !inside) ? cap : 0.f;  // the bound left for the certificates; outside: a cell from every target point
     if (inside) {
@@ -1228,6 +1246,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
       const bool ok = wave_exact_search(a.tgt, (const uint32_t *)(uintptr_t)rq, row_y, row_z, qx64, qy64, qz64, a.thr, lane, ep);
       if (lane == srcl) { verdict = ok ? O3D_CORR_CANDIDATE : O3D_CORR_NONE; bpos = ep; }  // lbn stays 0: searched again next pass
     }
+    SRCH_T(5)
     // issue the gathers for this trip's candidates; they are consumed in the next trip (or after the loop)
     use_p = verdict == O3D_CORR_CANDIDATE;
     i_p = i;
@@ -1270,6 +1289,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
       a.lb[i] = lbn;
     }
     wave_lds_sync();  // the next iteration rewrites the wavefront's LDS state
+    SRCH_T(6)
   }
   if (nq > 0) consume();
   __syncthreads();
@@ -2399,6 +2419,17 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
 #undef O3D_LAUNCH_EST
   O3D_HIP(ctx, hipGetLastError());
   if (ctx->tail_check && pl.tail && !check_done) O3D_TRY(o3d_tail_check_after(ctx, ctx->stream, nparts, dev_sums_out, "pass"));
+#if O3D_SRCH_PROF
+  {
+    unsigned long long hp[8];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_srch_prof), sizeof(hp));
+    fprintf(stderr, "search phases (M wave-cycles): head %.1f consume %.1f own-scan %.1f listing %.1f queue %.1f verdict %.1f tail %.1f\n", hp[0] * 1e-6,
+            hp[1] * 1e-6, hp[2] * 1e-6, hp[3] * 1e-6, hp[4] * 1e-6, hp[5] * 1e-6, hp[6] * 1e-6);
+    for (auto &v : hp) v = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_srch_prof), hp, sizeof(hp));
+  }
+#endif
   return O3D_OK;
 }
 
