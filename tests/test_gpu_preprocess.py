@@ -423,3 +423,28 @@ def test_estimate_normals_with_eigen_solver(ctx, oracle, mode):
     again = geometry.PointCloud(pts)
     again.EstimateNormals(sp, ctx=ctx)
     assert np.array_equal(again.normals_, fast.normals_)
+
+
+def test_hybrid_normals_where_the_counting_kernel_hands_over(ctx, oracle):
+    """The hand-over paths of k_estimate_normals_hist in hybrid mode, each against the oracle: (a) more candidates inside the
+    radius than a lane can note down (255) -- a dense blob with a radius that holds ~600 points: every point goes to the
+    heap kernel, and until it gets there the counting kernel must work on a consistent part of its candidates (counting on
+    after the notes stopped left list places unwritten in round 3: stale LDS used as positions, a memory fault);
+    (b) more than 8 candidates in the slice of the k-th nearest -- a ring of 24 points at nearly the same distance from a
+    centre, with max_nn cutting through the ring; (c) both kinds mixed with ordinary points in one cloud, so that wavefronts
+    hold lanes of every kind."""
+    geometry = _geo()
+    rng = np.random.default_rng(23)
+    blob = rng.random((6000, 3))                                    # 6000 points per unit cube
+    ang_a, ang_b = rng.random(10) * 2 * np.pi, rng.random(24) * 2 * np.pi
+    ring = lambda rho, ang: np.stack([rho * np.cos(ang), rho * np.sin(ang), rho * 0.05 * rng.standard_normal(len(ang))], 1)  # noqa: E731
+    shell = np.concatenate([ring(0.02, ang_a), ring(0.035, ang_b)]) + 5.0   # 24 points of the outer ring share a slice of d2
+    centre = np.array([[5.0, 5.0, 5.0]])
+    plain = rng.random((3000, 3)) * np.array([4.0, 4.0, 0.05]) + np.array([10.0, 0.0, 0.0])    # a thin sheet
+    for pts, radius, k in ((blob, 0.3, 30), (np.concatenate([centre, shell]), 0.05, 20),
+                           (np.concatenate([blob, centre, shell, plain]), 0.3, 30)):
+        pc = geometry.PointCloud(pts)
+        pc.EstimateNormals(geometry.KDTreeSearchParamHybrid(radius, k), ctx=ctx)
+        ref = oracle.estimate_normals(pts, oracle.HYBRID, k, radius)
+        ok = _normals_close(pc.normals_, ref, 1e-9)
+        assert ok.mean() > 0.999, "mismatching normals: %d of %d" % ((~ok).sum(), len(ok))
