@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
 //   place   the lane's notes are read back: those of lower slices go straight to their slice's place in the list
 //           (slices are ordered, so the list is ordered up to the order inside a slice), those of slice b* to a short
 //           boundary list.  (Rounds 1-2 walked the block a second time here and computed every distance twice: 43 % of
-//           the kernel's wave cycles; with the notes the kernel takes 7.0 ms instead of 8.0 at 10 M points.)
+//           the kernel's wave cycles; with the notes the kernel takes 6.8 ms instead of 7.9 at 10 M points.)
 //   finish  the boundary list is sorted by a fixed network and its first k - (number below) entries appended; the order
 //           inside the slices is repaired by odd-even transposition rounds until a round moves nothing (two or three).
 // Keys are the distances rounded to float as in the heap; equal keys are ordered by the exact fp64 distances, then by
@@ -716,8 +716,8 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals(const double4 *_
 // stream -- VALU busy 26 % of its cycles, 42 % spent in s_waitcnt.  Issuing the next batch's loads before the current batch is
 // worked through: 9.9 -> 7.9 ms.  Sharing a batch between the lanes of one cell through LDS (8 x fewer loads): no gain, so
 // the load path is not the limit even though its data-return unit reads 77 % busy.  Batching the LDS atomics of the
-// placing, batching the transposition's pairs, wave-compacted notes with cooperative placing, deferring the notes'
-// stores: each between 0 and 6 % slower.
+// placing, batching the transposition's pairs, an insertion sort in its place, wave-compacted notes with cooperative
+// placing, deferring the notes' stores: each between 0 and 6 % slower.
 constexpr int kHistBins = 32;
 constexpr int kBoundaryCap = 8;
 constexpr int kHistMaxKnn = 64;
