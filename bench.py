@@ -94,6 +94,9 @@ def main():
                     help="the timed region is repeated this many times back to back (value = median block), steps iterations each")
     ap.add_argument("--search", default="f32", choices=["f32", "f64"],
                     help="f32: fp32 prefilter search + fp64 confirmation + exact fixup (default); f64: per-lane fp64 search")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the rehearsal and the timed registrations (no steady-state, default-criteria, fresh-30 or hard-scene "
+                         "legs): under rocprofv3 --kernel-trace --stats the average k_icp_pass duration is then roofline.kernel_ms")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank under torch.distributed.run: still run pass -> RCCL all-gather -> solve (rehearsal of N > 1)")
     args = ap.parse_args()
@@ -205,7 +208,7 @@ def main():
     # The converged regime for comparison with earlier rounds (their `value`): the same registration kept going, K more
     # iterations timed once its first W + 3 have passed (every match certified, no search).
     steady = None
-    if True:
+    if not args.timed_only:
         total = args.warmup + 3 + args.steps
         icp.setup(d_src, d_tgt, d_nrm, radius, np.eye(4), est, reg.ICPConvergenceCriteria(0.0, 0.0, total), n)
         for _ in range(1 + args.warmup + 3):
@@ -240,10 +243,13 @@ def main():
         r_ = engine.sess.finish(corr_out=corr)
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0), r_
-    default_call(d_src, d_tgt, d_nrm, radius)
-    default_ms, default_res = default_call(d_src, d_tgt, d_nrm, radius)
-    fresh30_ms = None
-    if args.steps != 30:
+    default_ms, default_res, fresh30_ms = None, None, None
+    if not args.timed_only:
+        default_call(d_src, d_tgt, d_nrm, radius)
+        default_ms, default_res = default_call(d_src, d_tgt, d_nrm, radius)
+    if args.timed_only:
+        pass
+    elif args.steps != 30:
         t30 = [fresh_registration(d_src, d_tgt, d_nrm, radius, 30, n, timed_profile=False)[0] for _ in range(3)]
         fresh30_ms = 1e3 * float(np.median(t30))
     else:
@@ -252,7 +258,7 @@ def main():
     # A scene that keeps moving: rotation 1 degree, translation 6 spacings, search radius 4 spacings -- most
     # passes search a large part of the cloud instead of certifying it.  Generated on the device (same generator).
     hard = None
-    if world == 1 and args.hard_scene and args.estimation == "p2plane":
+    if world == 1 and args.hard_scene and args.estimation == "p2plane" and not args.timed_only:
         hs = synthetic.make_pair_device(ctx, n, n, cfg_id=33, theta_deg=1.0, tau_in_spacings=(4.0, -3.5, 2.9), want_normals=False)
         h_nrm = torch.empty((n, 3), dtype=torch.float64, device=dev)
         ctx.check(ctx._lib.o3d_estimate_normals(ctx.handle, hs["target"].data_ptr(), n, _lib.SEARCH_HYBRID, 30, 4.0 * s, _lib.MEM_DEVICE,
@@ -341,7 +347,7 @@ def main():
                 "fresh_call_0_0_30_iters_per_s": 30.0 / (fresh30_ms * 1e-3) if fresh30_ms else None,
                 "default_criteria_call_ms": default_ms,
                 "default_criteria_call": "ICPConvergenceCriteria(1e-6, 1e-6, 30): %d iterations; wall time of set-up (grid build, source "
-                                         "sort) + loop + results, buffers resident in HBM" % default_res.iterations_,
+                                         "sort) + loop + results, buffers resident in HBM" % (default_res.iterations_ if default_res else -1),
                 "steady_state": steady,
                 "hard_scene": hard,
             },
