@@ -812,7 +812,12 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
   extern __shared__ unsigned char smem[];
   const int lane = threadIdx.x;
   // the workgroup's part of `inside`: [kInsideCap][lane] (key, position) of the candidates the walk found inside the radius
-  uint2 *const mine = inside + (size_t)blockIdx.x * kInsideCap * kNrmBlock + lane;
+  // (a wave-uniform base and a 32-bit index: one address instruction per access)
+  uint2 *const mine_base = inside + (size_t)blockIdx.x * kInsideCap * kNrmBlock;
+  const uint32_t lane_bytes = (uint32_t)lane * (uint32_t)sizeof(uint2);
+  auto mine = [&](int slot) -> uint2 & {  // (a 32-bit byte offset from a scalar base)
+    return *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(mine_base) + ((uint32_t)slot * (uint32_t)(kNrmBlock * sizeof(uint2)) + lane_bytes));
+  };
   // [slot][lane] planes: keys, positions, histogram words (after the prefix: the slices' list places), boundary keys, boundary
   // positions
   float *lkey = reinterpret_cast<float *>(smem) + lane;
@@ -852,15 +857,14 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
         double d2 = ddx * ddx;
         d2 = d2 + ddy * ddy;
         d2 = d2 + ddz * ddz;
-        if (b.j + u < b.e && d2 < thr) {
-          if (n_in < kInsideCap) {  // (what is counted is what is noted: the slices and the list places stay consistent)
-            const float kf = (float)d2;
-            const int bin = (int)(kf * scale);
-            atomicAdd(&hist[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
-            mine[n_in * kNrmBlock] = make_uint2(__float_as_uint(kf), b.j + u);
-          }
-          n_in++;
+        const bool in = b.j + u < b.e && d2 < thr;
+        if (in && n_in < kInsideCap) {  // (what is counted is what is noted: the slices and the list places stay consistent)
+          const float kf = (float)d2;
+          const int bin = (int)(kf * scale);
+          atomicAdd(&hist[(bin >> 2) * kNrmBlock], 1u << ((bin & 3) * 8));
+          mine(n_in) = make_uint2(__float_as_uint(kf), b.j + u);
         }
+        n_in += in ? 1 : 0;
       }
     });
     // KNN search (thr = the cell side squared, what the 3x3x3 block is guaranteed to cover): with fewer than k points that
@@ -893,7 +897,7 @@ __global__ __launch_bounds__(kNrmBlock) void k_estimate_normals_hist(const doubl
       for (int i0 = 0; i0 < n_read; i0 += kHistLoads) {
         uint2 en[kHistLoads];
 #pragma unroll
-        for (int u = 0; u < kHistLoads; u++) en[u] = mine[min(i0 + u, kInsideCap - 1) * kNrmBlock];
+        for (int u = 0; u < kHistLoads; u++) en[u] = mine(min(i0 + u, kInsideCap - 1));
 #pragma unroll
         for (int u = 0; u < kHistLoads; u++) {
           if (i0 + u < n_read) {
