@@ -94,6 +94,9 @@ def main():
                     help="the timed region is repeated this many times back to back (value = median block), steps iterations each")
     ap.add_argument("--search", default="f32", choices=["f32", "f64"],
                     help="f32: fp32 prefilter search + fp64 confirmation + exact fixup (default); f64: per-lane fp64 search")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearse N ranks on fewer GPUs (ranks share devices, sums exchanged through the host): correctness "
+                         "of the N > 1 path only, its timings mean nothing")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the rehearsal and the timed registrations (no steady-state, default-criteria, fresh-30 or hard-scene "
                          "legs): under rocprofv3 --kernel-trace --stats the average k_icp_pass duration is then roofline.kernel_ms")
@@ -107,10 +110,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dist_backend == "gloo":  # rehearsal of several ranks on fewer GPUs: ranks share devices, the exchange goes through the host
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1 or (args.force_exchange and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: open3d_amd has no CPU fallback")
     dev = torch.device("cuda", local_rank)
@@ -334,6 +342,7 @@ def main():
                                 "cloud; median over the registrations" % (max(args.warmup, 1), blocks, args.steps),
                 "estimation": args.estimation,
                 "fitness": fitness,
+                "transformation_rowmajor": [float(v) for v in np.asarray(res.transformation_).reshape(-1)],
                 "inlier_rmse": res.inlier_rmse_,
                 "n_corr": n_corr_global,
                 "grid_build_ms": float(setup_ms[0]),

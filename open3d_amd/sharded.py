@@ -84,6 +84,18 @@ class ShardedICP:
         self.max_iter = criteria.max_iteration_
         self.engine.setup(src_shard, tgt, tgt_normals, max_dist, init, estimation, criteria, n_src_global)
 
+    def _all_gather(self):
+        """The iteration's one exchange.  RCCL ("nccl") gathers device tensors on the stream; gloo cannot gather device tensors,
+        so under gloo (CPU tests, and the rehearsal of several ranks on ONE GPU, bench.py --dist-backend gloo) a device tensor
+        goes through the host -- correct, synchronous, not a measurement."""
+        if self.local.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            loc = self.local.cpu()
+            allc = self.torch.empty(NSUMS * self.world, dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(allc, loc, group=self.group)
+            self.all.copy_(allc)
+        else:
+            self.dist.all_gather_into_tensor(self.all, self.local, group=self.group)
+
     def step(self):
         """One LOOP-A pass + estimate on every rank (enqueue only; no host synchronisation)."""
         if self.world == 1 and not self.force_exchange and hasattr(self.engine, "step_unsharded"):
@@ -91,7 +103,7 @@ class ShardedICP:
             return
         self.engine.pass_into(self.local)
         if self.world > 1 or self.force_exchange:
-            self.dist.all_gather_into_tensor(self.all, self.local, group=self.group)
+            self._all_gather()
             self.engine.solve_from(self.all, self.world)
         else:
             self.engine.solve_from(self.local, 1)
