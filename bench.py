@@ -396,6 +396,10 @@ def main():
             out["roofline"]["traffic_per_kind"] = per
             out["roofline"]["search_pass"]["traffic"] = (2.0 * tr["k_icp_search_coop"]["fetch_size_kb"]
                                                          + tr["k_icp_search_coop"]["write_size_kb"]) * 1024.0
+            if "exact_request_bytes" in tr:  # the same passes counted by request size (no correction factor involved)
+                ex = tr["exact_request_bytes"]
+                per_x = {k: ex["k_icp_pass_" + k]["read_bytes"] + ex["k_icp_pass_" + k]["write_bytes"] for k in ("search_all", "steady")}
+                out["roofline"]["traffic_by_request_size"] = (per_x["search_all"] + (args.steps - 1) * per_x["steady"]) / args.steps
             out["roofline"]["traffic_source"] = tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             n_sample = min(args.cpu_sample, n)
