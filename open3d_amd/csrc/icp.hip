@@ -818,14 +818,24 @@ __device__ __forceinline__ bool wave_exact_search(const double4 *__restrict__ tg
 // as it does in the first pass.
 
 // The wavefront's share of the source.  The grid is dealt round-robin over the 8 XCDs (workgroups b and b + 8 share one, and an
-// L2): XCD x owns the x-th eighth of the processing order, and its wavefronts sweep that eighth TOGETHER -- trip t of the XCD's
-// w-th wavefront is block t * W + w of 64 consecutive positions (W wavefronts per XCD).  The wavefronts that run at the same
+// L2), and ALL its wavefronts sweep the processing order together: trip t covers the window of 8 * W consecutive blocks of 64
+// positions that starts at block t * 8 * W (W wavefronts per XCD: 4096 blocks, 262144 positions, with the product's grid), and
+// inside the window XCD x takes the x-th eighth -- its w-th wavefront block x * W + w.  The wavefronts that run at the same
 // time are then neighbours on the Hilbert curve: a candidate line, table row or matched record one of them has fetched is in
-// the XCD's L2 when the next one wants it.  (With one contiguous segment per wavefront the 512 wavefronts of an XCD worked at
-// 512 places far apart; the L2 -- 4 MB -- could hold none of what neighbouring segments share, and a pass that searches
-// everything fetched 2.5 GB for the 1.1 GB it needs.)  k_icp_cert and k_icp_search_coop run on the same grid and walk the same
-// blocks; the work list and its counters are per wavefront: segment number = chunk * 4 + wavefront, PassArgs::seg_len list
-// places each (a multiple of 64, at least what the wavefront's blocks hold).
+// the XCD's L2 when the next one wants it, and the eight XCDs read eight adjoining stretches of every array.  History, all
+// measured (profiles/r03_l_*):
+//   one contiguous segment per wavefront   the 512 wavefronts of an XCD worked at 512 places far apart; the L2 -- 4 MB --
+//                                          could hold none of what neighbouring segments share, and a pass that searches
+//                                          everything fetched 2.5 GB for the 1.1 GB it needs;
+//   one eighth of the ORDER per XCD        (swept by that XCD's wavefronts together) eight fronts 1.25 M positions apart
+//                                          instead of one: the same fabric bytes, but every pass 3-13 % slower than with the
+//                                          single window;
+//   shorter runs inside the window         (8 ... 64 consecutive blocks per XCD, interleaved) as fast as the eighths of the
+//                                          window, but neighbouring runs meet in different L2s: 1.77 GB instead of 1.37 GB
+//                                          fetched by a pass that searches everything.
+// k_icp_cert and k_icp_search_coop run on the same grid and walk the same blocks; the work list and its counters are per
+// wavefront: segment number = chunk * 4 + wavefront, PassArgs::seg_len list places each (a multiple of 64, at least what the
+// wavefront's blocks hold).
 struct WaveRange {
   unsigned chunk, seg;
   int64_t first, stride, end;  // positions first + t * stride + lane, t = 0, 1, ..., while below end
@@ -838,14 +848,10 @@ __device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, 
   const unsigned per_xcd = gdim >> 3;  // workgroups per XCD (the launch grids are multiples of 8)
   r.chunk = xcd * per_xcd + wg;        // partial row of the workgroup
   r.seg = r.chunk * 4u + (threadIdx.x >> 6);
-  const int64_t blocks = (n_src + O3D_WAVE - 1) / O3D_WAVE;
-  const int64_t eighth = (blocks + 7) / 8;  // blocks per XCD
   const int64_t w = (int64_t)wg * 4 + (threadIdx.x >> 6), W = (int64_t)per_xcd * 4;
-  int64_t b_end = (int64_t)(xcd + 1) * eighth;
-  if (b_end > blocks) b_end = blocks;
-  r.first = ((int64_t)xcd * eighth + w) * O3D_WAVE;
-  r.stride = W * O3D_WAVE;
-  r.end = b_end * O3D_WAVE < n_src ? b_end * O3D_WAVE : n_src;
+  r.first = ((int64_t)xcd * W + w) * O3D_WAVE;  // = seg * 64: wavefront number seg takes block seg of every window
+  r.stride = W * 8 * O3D_WAVE;
+  r.end = n_src;
   if (r.first > r.end) r.first = r.end;
   // (the last block of the cloud may be short)
   const int64_t span = r.end - r.first;
@@ -2327,9 +2333,9 @@ static PassPlan plan_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve, bo
   pa.cert_row0 = pl.grows;
   {  // one segment per wavefront, the same for both kernels
     const int64_t nseg = 4 * (int64_t)pl.grows;
-    // (a wavefront takes every W-th block of 64 of its XCD's eighth, W = nseg / 8: see wave_range)
-    const int64_t blocks = (ctx->n_src + O3D_WAVE - 1) / O3D_WAVE, eighth = (blocks + 7) / 8, W = nseg / 8;
-    pa.seg_len = ((eighth + W - 1) / W) * O3D_WAVE;
+    // (a wavefront takes one block of 64 out of every window of nseg blocks: see wave_range)
+    const int64_t blocks = (ctx->n_src + O3D_WAVE - 1) / O3D_WAVE;
+    pa.seg_len = ((blocks + nseg - 1) / nseg) * O3D_WAVE;
     if (pa.seg_len < O3D_WAVE) pa.seg_len = O3D_WAVE;
   }
   pa.grid_x = pl.grows;
