@@ -260,6 +260,9 @@ O3D_API int o3d_debug_grid_info(const o3d_ctx *ctx, double out[10]);
 O3D_API int o3d_debug_inject_bound_violation(o3d_ctx *ctx, unsigned int count);
 /* Processing order of the source shard after o3d_icp_setup: out[p] = caller's index of the p-th processed point. */
 O3D_API int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out);
+/* Tuning hook, no reference counterpart: out[p] = where the match of the p-th processed point sits in the cell-sorted target
+ * (0xFFFFFFFF: none), as the last pass left it -- the addresses the certifying pass gathers from (scripts/micro). */
+O3D_API int o3d_debug_get_match_positions(o3d_ctx *ctx, uint32_t *host_out);
 /* Timing breakdown of the last setup (milliseconds, HIP events): [0] grid build, [1] source upload+sort. */
 O3D_API int o3d_icp_get_setup_ms(o3d_ctx *ctx, double out_ms[2]);
 

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "o3d_debug_grid_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "o3d_debug_inject_bound_violation": (C.c_int, [C.c_void_p, C.c_uint]),
     "o3d_debug_get_source_perm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "o3d_debug_get_match_positions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "o3d_icp_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "o3d_icp_profile_read": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
     "o3d_icp_profile_read2": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int)]),
@@ -229,6 +230,11 @@ class Context:
     def source_perm(self, n_src):
         out = np.empty(n_src, np.uint32)
         self.check(self._lib.o3d_debug_get_source_perm(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def match_positions(self, n_src):
+        out = np.empty(n_src, np.uint32)
+        self.check(self._lib.o3d_debug_get_match_positions(self._h, C.c_void_p(out.ctypes.data)))
         return out
 
     def tile_stats(self, reset=True):

@@ -775,6 +775,16 @@ int o3d_debug_get_source_perm(o3d_ctx *ctx, uint32_t *host_out) {
   return O3D_OK;
 }
 
+int o3d_debug_get_match_positions(o3d_ctx *ctx, uint32_t *host_out) {
+  if (!ctx || !host_out) return O3D_ERR_INVALID_ARG;
+  O3D_LOCK(ctx);
+  if (!ctx->icp_ready || !ctx->pos_sorted) return o3d_fail(ctx, O3D_ERR_STATE, "no source loaded");
+  DeviceGuard guard(ctx->device);
+  O3D_HIP(ctx, o3d_d2h(ctx, host_out, ctx->pos_sorted, sizeof(uint32_t) * (size_t)ctx->n_src));
+  O3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return O3D_OK;
+}
+
 int o3d_debug_tile_stats(o3d_ctx *ctx, uint64_t out[8], int reset) {
   if (!ctx || !out) return O3D_ERR_INVALID_ARG;
   O3D_LOCK(ctx);

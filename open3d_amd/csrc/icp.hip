@@ -28,6 +28,17 @@
 #ifndef O3D_COUNT_STATIC
 #define O3D_COUNT_STATIC 0
 #endif
+#ifndef O3D_PASS_PROF
+#define O3D_PASS_PROF 0
+#endif
+#if O3D_PASS_PROF  // profile build only (scripts/pass_phases.sh): when every wavefront of k_icp_pass passes its milestones (100 MHz
+                   // clock; plain stores to the wavefront's own slots -- atomics on shared counters cost more than the pass)
+#define O3D_PASS_MARKS 8
+__device__ unsigned long long g_pass_t[4 * O3D_MAX_GRID][O3D_PASS_MARKS];
+#define PASS_MARK(i) { if ((threadIdx.x & 63) == 0) g_pass_t[blockIdx.x * 4 + (threadIdx.x >> 6)][i] = wall_clock64(); }
+#else
+#define PASS_MARK(i)
+#endif
 #if O3D_SRCH_PROF  // profile build only (scripts/search_phases.sh): wave cycles per phase of a search trip
 __device__ unsigned long long g_srch_prof[8];
 #define SRCH_T(i) { const long long t_now = clock64(); if (lane == 0) atomicAdd(&g_srch_prof[i], (unsigned long long)(t_now - t_prev)); t_prev = clock64(); }
@@ -426,22 +437,34 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_search(PassArgs a, GridParams
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same sums on the matrix cores.  Every sum of the estimate is an entry of  S = sum_p v(p) v(p)^T  for a short
-// per-correspondence vector v:
-//   point-to-plane  v = (J0..J5, r, d2, 1):  JTJ = S[0..5][0..5], JTr = S[a][6], sum r^2 = S[6][6], sum d2 = S[7][8], n = S[8][8]
-//   point-to-point  v = (s - c, t - c, 1, d2): sum (s-c) = S[0..2][6], sum (t-c) = S[3..5][6], sum (t-c)(s-c)^T = S[3+a][b],
-//                                              sum |s-c|^2 = S[0][0] + S[1][1] + S[2][2], sum d2 = S[7][6], n = S[6][6]
-// A wavefront stages the 64 vectors of one trip in LDS (component-major) and issues 16 v_mfma_f64_16x16x4_f64, each a
-// rank-4 update with A[i][k] = B[k][i] = v_i(point 4m + k): lane l supplies component l & 15 of point 4m + (l >> 4) for
-// both operands.  The running 16 x 16 fp64 matrix is 4 doubles per lane instead of 30 per-lane accumulators, which is
-// what lets the accumulation ride along in the search kernel (k_icp_search_coop) without costing it its occupancy.
+// The same sums on the matrix cores.  Every sum of the estimate is an entry of  S = sum_p a(p) b(p)^T  for two short
+// per-correspondence vectors that differ in their last component only:
+//   point-to-plane  a = (J0..J5, r, 1), b = (J0..J5, r, d2):  JTJ = S[0..5][0..5], JTr = S[c][6], sum r^2 = S[6][6], sum d2 = S[7][7]
+//   point-to-point  a = b = (s - c, t - c, 1, d2): sum (s-c) = S[0..2][6], sum (t-c) = S[3..5][6], sum (t-c)(s-c)^T = S[b][3+a],
+//                                                  sum |s-c|^2 = S[0][0] + S[1][1] + S[2][2], sum d2 = S[6][7]
+// and the number of correspondences is counted with the wavefront's ballot (an integer, exact).  Only the upper triangle of
+// 4 x 4 tiles is needed -- (0,0), (0,1), (1,1) -- and v_mfma_f64_4x4x4_4b_f64 computes four independent 4 x 4 x 4 products
+// at once: a wavefront stages the 64 vector pairs of one trip in LDS (component-major) and issues 12 of them, each adding
+// 4 points to one tile in each of its four blocks (the blocks' partial tiles are added when the pass ends).  Lane l
+// supplies A[block (l >> 2) & 3][row l & 3][k = l >> 4] and B[block][column l & 3][k] and holds
+// D[block][row l >> 4][column l & 3] (scripts/micro/mfma_f64_4x4_layout.hip asks the hardware): one double per lane and
+// tile, three in all, instead of 30 per-lane accumulators -- which is what lets the accumulation ride along in the search
+// kernel (k_icp_search_coop) without costing it its occupancy.
+// Rounds 1-3 used 16 v_mfma_f64_16x16x4_f64 per trip on 9-component vectors: 16384 multiply-adds for the 3072 needed, and on
+// MI355X, whose fp64 matrix rate equals its fp64 vector rate, 1024 of the ~2800 cycles a SIMD spent per wavefront and trip
+// of the certifying pass (profiles/r03_m_*: that pass is bound by the SIMDs' fp64 issue, not by memory).  The 4 x 4 form
+// issues exactly the 3072: 192 cycles.
 // fp64 throughout; products are fused into the accumulation (the per-lane form rounds them first), which moves the
 // sums by a few ulp -- far inside the 1e-6 parity bar of the estimate, and the correspondences are not affected.
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int kVComp = 9;
-constexpr int kVStride = 68;  // doubles per component row: 64 points + padding that spreads the rows over the LDS banks
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+constexpr int kVComp = 9;     // staged rows: a0..a7 and b7
+constexpr int kVStride = 80;  // doubles per component row: 64 points + padding; 80 puts rows c and c + 1 on different halves of the banks
 struct VBuf {
   double v[kVComp][kVStride];
+};
+struct Sums {
+  double t00, t01, t11;  // the lane's entries of the tiles (0,0), (0,1), (1,1)
+  uint32_t n;            // correspondences (wave-uniform)
 };
 
 template <int EST>
@@ -455,11 +478,11 @@ __device__ __forceinline__ void make_v(double (&v)[kVComp], bool use, double x, 
     v[1] = z * n0 - x * n2;
     v[2] = x * n1 - y * n0;
     v[3] = n0; v[4] = n1; v[5] = n2;
-    v[6] = r; v[7] = d2; v[8] = 1.0;
+    v[6] = r; v[7] = 1.0; v[8] = d2;
   } else {
     v[0] = x - cx0; v[1] = y - cy0; v[2] = z - cz0;
     v[3] = p.x - cx0; v[4] = p.y - cy0; v[5] = p.z - cz0;
-    v[6] = 1.0; v[7] = d2; v[8] = 0.0;
+    v[6] = 1.0; v[7] = d2; v[8] = d2;
   }
   if (!use) {
 #pragma unroll
@@ -467,41 +490,41 @@ __device__ __forceinline__ void make_v(double (&v)[kVComp], bool use, double x, 
   }
 }
 
-// S += sum over the wavefront's 64 lanes of v v^T.  All 64 lanes must call it (lanes without a correspondence bring v = 0).
-__device__ __forceinline__ void mfma_rank64(VBuf &vb, int lane, const double (&v)[kVComp], v4f64 &S) {
+// S += sum over the wavefront's 64 lanes of a b^T (v = a0..a7, b7).  All 64 lanes must call it (lanes without a
+// correspondence bring zeros).
+__device__ __forceinline__ void mfma_rank64(VBuf &vb, int lane, const double (&v)[kVComp], Sums &S) {
   wave_lds_sync();  // the buffer may alias LDS the wavefront was reading until now
 #pragma unroll
   for (int c = 0; c < kVComp; c++) vb.v[c][lane] = v[c];
   wave_lds_sync();
-  const int comp = lane & 15, k = lane >> 4;
-  const double *col = &vb.v[comp < kVComp ? comp : 0][k];
-  // operands in batches of four (eight registers in flight instead of thirty-two, which would cost the kernels around this
-  // call their occupancy or push them into scratch memory)
+  const int c4 = lane & 3, pt = 4 * ((lane >> 2) & 3) + (lane >> 4);  // the lane's row / column of a tile; its point of a group of 16
+  const double *lo = &vb.v[c4][pt];                       // components 0..3
+  const double *hi_a = &vb.v[4 + c4][pt];                 // components 4..7 of a
+  const double *hi_b = &vb.v[c4 == 3 ? 8 : 4 + c4][pt];   // components 4..7 of b
 #pragma unroll
-  for (int m0 = 0; m0 < 16; m0 += 4) {
-    double a[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) a[u] = comp >= kVComp ? 0.0 : col[4 * (m0 + u)];
-#pragma unroll
-    for (int u = 0; u < 4; u++) S = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], a[u], S, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int g = 0; g < 4; g++) {  // points 16 g .. 16 g + 15: four per block
+    const double l = lo[16 * g], ha = hi_a[16 * g], hb = hi_b[16 * g];
+    S.t00 = __builtin_amdgcn_mfma_f64_4x4x4f64(l, l, S.t00, 0, 0, 0);
+    S.t01 = __builtin_amdgcn_mfma_f64_4x4x4f64(l, hb, S.t01, 0, 0, 0);
+    S.t11 = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, hb, S.t11, 0, 0, 0);
   }
   wave_lds_sync();
 }
 
-// One correspondence's contribution to S: one vector for point-to-point / point-to-plane, two (geometric, photometric)
+// One correspondence's contribution to S: one vector pair for point-to-point / point-to-plane, two (geometric, photometric)
 // for coloured ICP.  Every lane of the wavefront must call it.
 template <int EST>
-__device__ __forceinline__ void push_sums(VBuf &vb, int lane, v4f64 &S, bool use, double x, double y, double z, const double4 &p,
+__device__ __forceinline__ void push_sums(VBuf &vb, int lane, Sums &S, bool use, double x, double y, double z, const double4 &p,
                                           double n0, double n1, double n2, double d2, double cx0, double cy0, double cz0,
                                           const double4 &tc, double is, double slg, double slp) {
   double v[kVComp];
+  S.n += (uint32_t)__popcll(__ballot(use));
   if (EST == O3D_EST_COLORED_ICP) {
     double Jg[6], Jp[6], rg, rp;
     colored_rows(x, y, z, p, n0, n1, n2, tc, is, slg, slp, Jg, rg, Jp, rp);
 #pragma unroll
     for (int c = 0; c < 6; c++) v[c] = use ? Jg[c] : 0.0;
-    v[6] = use ? rg : 0.0; v[7] = use ? d2 : 0.0; v[8] = use ? 1.0 : 0.0;
+    v[6] = use ? rg : 0.0; v[7] = use ? 1.0 : 0.0; v[8] = use ? d2 : 0.0;
     mfma_rank64(vb, lane, v, S);
 #pragma unroll
     for (int c = 0; c < 6; c++) v[c] = use ? Jp[c] : 0.0;
@@ -513,10 +536,11 @@ __device__ __forceinline__ void push_sums(VBuf &vb, int lane, v4f64 &S, bool use
   }
 }
 
-// Entry (row, col) of S that sum k of the partial row comes from (k < 30); point-to-point sum 15 is the trace term.
+// Entry (row, col), row <= col, of S that sum k of the partial row comes from (k < 30, not the count); point-to-point sum 15
+// is the trace term.  (15, 15) stands for "always zero".
 template <int EST>
 __device__ __forceinline__ void sum_source(int k, int &row, int &col) {
-  row = 15; col = 15;  // an entry that is always zero
+  row = 15; col = 15;
   if (EST != O3D_EST_POINT_TO_POINT) {
     if (k < 21) {
       int a = 0, rem = k;
@@ -524,34 +548,50 @@ __device__ __forceinline__ void sum_source(int k, int &row, int &col) {
       row = a; col = a + rem;
     } else if (k < 27) { row = k - 21; col = 6; }
     else if (k == 27) { row = 6; col = 6; }
-    else if (k == O3D_SUM_D2) { row = 7; col = 8; }
-    else if (k == O3D_SUM_NC) { row = 8; col = 8; }
+    else if (k == O3D_SUM_D2) { row = 7; col = 7; }
   } else {
     if (k < 6) { row = k; col = 6; }
-    else if (k < 15) { row = 3 + (k - 6) / 3; col = (k - 6) % 3; }
-    else if (k == O3D_SUM_D2) { row = 7; col = 6; }
-    else if (k == O3D_SUM_NC) { row = 6; col = 6; }
+    else if (k < 15) { row = (k - 6) % 3; col = 3 + (k - 6) / 3; }  // (t-c)_a (s-c)_b = S[b][3 + a]: a = b is symmetric
+    else if (k == O3D_SUM_D2) { row = 6; col = 7; }
   }
 }
 
-// Combine the workgroup's wavefronts in a fixed order and write one 32-double partial row.
-// C/D map of v_mfma_f64_16x16x4_f64: register r of lane l holds S[(l >> 4) + 4 r][l & 15].
-template <int EST>
-__device__ __forceinline__ void mfma_reduce_store(const v4f64 &S, double (*red)[16][16], double *__restrict__ partials, unsigned chunk) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Combine the blocks of every tile and the workgroup's wavefronts in a fixed order and write one 32-double partial row.
+constexpr int kRedDoubles = 3 * 64;  // per wavefront; the four counts follow the four wavefronts' tiles
+__device__ __forceinline__ double red_entry(const double *red, int row, int col) {
+  if (row > 7 || col > 7) return 0.0;
+  const int tile = (row >> 2) + (col >> 2), at = 16 * (row & 3) + (col & 3);  // D[block][row][col] sits in lane 16 row + 4 block + col
+  double v = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) red[wave][(lane >> 4) + 4 * r][lane & 15] = S[r];
+  for (int w = 0; w < O3D_BLOCK / O3D_WAVE; w++) {
+    const double *t = red + w * kRedDoubles + tile * 64 + at;
+    const double s = ((t[0] + t[4]) + t[8]) + t[12];
+    v = w == 0 ? s : v + s;
+  }
+  return v;
+}
+template <int EST>
+__device__ __forceinline__ void mfma_reduce_store(const Sums &S, double *red /* 4 * kRedDoubles + 4 doubles of LDS */, double *__restrict__ partials,
+                                                  unsigned chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  red[wave * kRedDoubles + lane] = S.t00;
+  red[wave * kRedDoubles + 64 + lane] = S.t01;
+  red[wave * kRedDoubles + 128 + lane] = S.t11;
+  if (lane == 0) red[(O3D_BLOCK / O3D_WAVE) * kRedDoubles + wave] = (double)S.n;
   __syncthreads();
   if (threadIdx.x < O3D_NSUMS) {
     const int k = threadIdx.x;
     double v = 0.0;
-    if (k < 30) {
+    if (k == O3D_SUM_NC) {
+      const double *c = red + (O3D_BLOCK / O3D_WAVE) * kRedDoubles;
+      v = ((c[0] + c[1]) + c[2]) + c[3];
+    } else if (k < 30) {
       int row, col;
       sum_source<EST>(k, row, col);
-      v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+      v = red_entry(red, row, col);
       if (EST == O3D_EST_POINT_TO_POINT && k == 15) {
         v = 0.0;
-        for (int d = 0; d < 3; d++) v += ((red[0][d][d] + red[1][d][d]) + red[2][d][d]) + red[3][d][d];
+        for (int d = 0; d < 3; d++) v += red_entry(red, d, d);
       }
     }
     store_partial_row(partials, chunk, k, v);  // pass_tail may read it from another XCD
@@ -565,13 +605,13 @@ __global__ __launch_bounds__(O3D_BLOCK) void k_icp_accumulate_mfma(PassArgs a) {
   if (a.st->done) return;
   // the staging buffers and the final cross-wavefront combine share LDS (the combine starts after the last trip)
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE)];
-  static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
+  static_assert(sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * ((O3D_BLOCK / O3D_WAVE) * kRedDoubles + O3D_BLOCK / O3D_WAVE), "combine buffer must fit");
   VBuf *vbs = reinterpret_cast<VBuf *>(lds_raw);
-  double (*red)[16][16] = reinterpret_cast<double (*)[16][16]>(lds_raw);
+  double *red = reinterpret_cast<double *>(lds_raw);
   const int lane = threadIdx.x & 63;
   VBuf &vb = vbs[threadIdx.x >> 6];
   const double cx0 = a.st->centre[0], cy0 = a.st->centre[1], cz0 = a.st->centre[2];
-  v4f64 S = {0.0, 0.0, 0.0, 0.0};
+  Sums S = {0.0, 0.0, 0.0, 0u};
   const int64_t per = ((a.n_src + gridDim.x - 1) / gridDim.x + O3D_BLOCK - 1) / O3D_BLOCK * O3D_BLOCK;
   const unsigned chunk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t beg = (int64_t)chunk * per;
@@ -862,8 +902,8 @@ __device__ __forceinline__ WaveRange wave_range(int64_t n_src, int64_t seg_len, 
 }
 
 constexpr size_t kCertLdsBytes = sizeof(VBuf) * (O3D_BLOCK / O3D_WAVE);
-static_assert(kCertLdsBytes >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "combine buffer must fit");
-template <int EST, bool STREAM>
+static_assert(kCertLdsBytes >= sizeof(double) * ((O3D_BLOCK / O3D_WAVE) * kRedDoubles + O3D_BLOCK / O3D_WAVE), "combine buffer must fit");
+template <int EST, bool STREAM, bool TN /* the target has the 48-byte point + normal records (PassArgs::tn) */>
 __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_raw /* kCertLdsBytes, 16-byte aligned */) {
   if (a.st->done) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -883,7 +923,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   load_update(a.st, T, w);
   const float thrf = (float)a.thr;
   constexpr bool stream = STREAM;  // (a run-time flag was merged into one path by the compiler, which dropped the hint)
-  v4f64 S = {0.0, 0.0, 0.0, 0.0};
+  Sums S = {0.0, 0.0, 0.0, 0u};
   unsigned long long ncert = 0;
   uint32_t nwork = 0;  // wave-uniform
   // The loop is software-pipelined over three trips: while trip t is worked through, the matched records of trip t + 1 are
@@ -897,9 +937,11 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     uint32_t pprev;
     float lbv;
   };
-  struct StageB {  // what is gathered: the matched record
-    double4 p, tc;
-    double n0, n1, n2, is;
+  struct StageB {  // what is gathered: the matched record -- point and normal as three 16-byte pieces (p.x p.y | p.z n0 | n1 n2)
+    v2f64 q0, q1, q2;
+    double4 p4;  // (point-to-point: the 32-byte point alone)
+    double4 tc;
+    double is;
   };
   const int64_t i_last = wr.end - 1;  // (only used when the wavefront has a trip: wr.first < wr.end)
   auto load_a = [&](int64_t base) {
@@ -918,20 +960,26 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     return s;
   };
   auto load_b = [&](const StageA &s, int64_t base) {
-    StageB r;
+    StageB r = {};
     int64_t i = base + lane;
     if (i > i_last) i = i_last;
     const size_t at = s.pprev != O3D_POS_NONE ? (size_t)s.pprev : 0;  // (no previous match: record 0, not used)
-    r.tc = make_double4(0.0, 0.0, 0.0, 0.0);
-    r.n0 = r.n1 = r.n2 = r.is = 0.0;
-    if (EST != O3D_EST_POINT_TO_POINT && a.tn) {  // one 48-byte record instead of two gathers of 32 and 24 bytes
-      const double2 r0 = a.tn[3 * at], r1 = a.tn[3 * at + 1], r2 = a.tn[3 * at + 2];
-      r.p = make_double4(r0.x, r0.y, r1.x, 0.0);  // (the index in p.w is not needed here: a certified entry is not rewritten)
-      r.n0 = r1.y; r.n1 = r2.x; r.n2 = r2.y;
+    if (EST != O3D_EST_POINT_TO_POINT && TN) {
+      // one 48-byte record instead of two gathers of 32 and 24 bytes, read as exactly three 16-byte loads (as HIP's double2
+      // the compiler took the record apart into one 16-byte and four 8-byte loads; the L1 counts 64 accesses for a
+      // wavefront's 8-byte load as for its 16-byte load -- TCP_TOTAL_ACCESSES, scripts/micro -- so that was 320 accesses per
+      // trip for the 192 needed, of 550 in all: 1.5 % of the pass)
+      const v2f64 *rec = reinterpret_cast<const v2f64 *>(a.tn) + 3 * at;
+      r.q0 = rec[0]; r.q1 = rec[1]; r.q2 = rec[2];
+    } else if (EST == O3D_EST_POINT_TO_POINT) {
+      r.p4 = a.tgt[at];
     } else {
-      r.p = a.tgt[at];
+      const double4 p = a.tgt[at];
+      r.q0 = v2f64{p.x, p.y};
+      r.q1 = v2f64{p.z, 0.0};
+      r.q2 = v2f64{0.0, 0.0};
       if (EST != O3D_EST_POINT_TO_POINT) {
-        r.n0 = a.nrm[3 * at]; r.n1 = a.nrm[3 * at + 1]; r.n2 = a.nrm[3 * at + 2];
+        r.q1.y = a.nrm[3 * at]; r.q2.x = a.nrm[3 * at + 1]; r.q2.y = a.nrm[3 * at + 2];
       }
     }
     if (EST == O3D_EST_COLORED_ICP) { r.tc = a.tcol[at]; r.is = a.sint[i]; }
@@ -944,6 +992,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     a1 = load_a(wr.first + wr.stride);
     r0 = load_b(a0, wr.first);
   }
+  PASS_MARK(1)
   for (int64_t base = wr.first; base < wr.end; base += wr.stride) {
     r1 = load_b(a1, base + wr.stride);
     a2 = load_a(base + 2 * wr.stride);
@@ -954,8 +1003,9 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     const float lbv = valid ? a0.lbv : 0.f;
     float moved = 0.f;
     const bool has_prev = valid && pprev != O3D_POS_NONE;
-    const double4 p = r0.p, tc = r0.tc;
-    const double n0 = r0.n0, n1 = r0.n1, n2 = r0.n2, is = r0.is;
+    // (p.w, the index, is not needed: a certified entry is not rewritten)
+    const double4 p = EST == O3D_EST_POINT_TO_POINT ? r0.p4 : make_double4(r0.q0.x, r0.q0.y, r0.q1.x, 0.0), tc = r0.tc;
+    const double n0 = r0.q1.y, n1 = r0.q2.x, n2 = r0.q2.y, is = r0.is;
     a0 = a1; a1 = a2; r0 = r1;
     // A point the update leaves where it is, bit for bit, is not written back, and its bound stays as it stands (it was
     // written for exactly this position).  Point-to-plane ICP converges quadratically: on the headline scene the updates are
@@ -1015,12 +1065,14 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     if (a.stats) ncert += __popcll(__ballot(certified));
     push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
   }
+  PASS_MARK(2)
   if (lane == 0) {
     a.work_count[wr.seg] = nwork;
     if (a.stats && ncert) atomicAdd(&a.ctr[O3D_CTR_CERTIFIED], ncert);
   }
   __syncthreads();  // every wavefront is done with its staging buffer
-  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
+  PASS_MARK(3)
+  mfma_reduce_store<EST>(S, reinterpret_cast<double *>(lds_raw), a.partials, a.cert_row0 + wr.chunk);
 }
 
 // The arguments of a pass's kernels as they sit in device memory for the lock-step form of the loop (o3d_launch_pass_gang):
@@ -1033,23 +1085,27 @@ struct PassLaunch {
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert(PassArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
-  cert_body<EST, false>(a, lds_raw);
+  if (a.tn) cert_body<EST, false, true>(a, lds_raw);
+  else cert_body<EST, false, false>(a, lds_raw);
 }
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_s(PassArgs a) {  // PassArgs::stream
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
-  cert_body<EST, true>(a, lds_raw);
+  if (a.tn) cert_body<EST, true, true>(a, lds_raw);
+  else cert_body<EST, true, false>(a, lds_raw);
 }
 // ... and for several registrations in lock step (o3d_registration_icp_batch): blockIdx.y names the registration
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch(const PassLaunch *__restrict__ pl) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
-  cert_body<EST, false>(pl[blockIdx.y].a, lds_raw);
+  if (pl[blockIdx.y].a.tn) cert_body<EST, false, true>(pl[blockIdx.y].a, lds_raw);
+  else cert_body<EST, false, false>(pl[blockIdx.y].a, lds_raw);
 }
 template <int EST>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_cert_batch_s(const PassLaunch *__restrict__ pl) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kCertLdsBytes];
-  cert_body<EST, true>(pl[blockIdx.y].a, lds_raw);
+  if (pl[blockIdx.y].a.tn) cert_body<EST, true, true>(pl[blockIdx.y].a, lds_raw);
+  else cert_body<EST, true, false>(pl[blockIdx.y].a, lds_raw);
 }
 
 // The cooperative search (see above CoopWave).  PassArgs::listed: the queries are the work list k_icp_cert left behind
@@ -1060,11 +1116,11 @@ template <int EST, bool TN>
 __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridParams &gp, CoopWave *wls /* one per wavefront */) {
   const unsigned gdim = (unsigned)a.grid_x;
   if (blockIdx.x >= gdim || a.st->done) return;
-  static_assert(sizeof(CoopWave) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * (O3D_BLOCK / O3D_WAVE) * 256, "the final combine reuses this LDS");
+  static_assert(sizeof(CoopWave) * (O3D_BLOCK / O3D_WAVE) >= sizeof(double) * ((O3D_BLOCK / O3D_WAVE) * kRedDoubles + O3D_BLOCK / O3D_WAVE), "the final combine reuses this LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   CoopWave &wl = wls[tid >> 6];
   const double cx0 = uniform_f64(a.st->centre[0]), cy0 = uniform_f64(a.st->centre[1]), cz0 = uniform_f64(a.st->centre[2]);
-  v4f64 S = {0.0, 0.0, 0.0, 0.0};
+  Sums S = {0.0, 0.0, 0.0, 0u};
   const bool listed = a.listed && !a.st->skip_cert;
   const int apply = listed ? 0 : a.st->apply_update;
   double T[12], w[4];
@@ -1318,7 +1374,7 @@ __device__ __forceinline__ void search_coop_body(const PassArgs &a, const GridPa
   }
   if (nq > 0) consume();
   __syncthreads();
-  mfma_reduce_store<EST>(S, reinterpret_cast<double (*)[16][16]>(wls), a.partials, wr.chunk);
+  mfma_reduce_store<EST>(S, reinterpret_cast<double *>(wls), a.partials, wr.chunk);
   pass_tail(a, reinterpret_cast<double *>(wls), wr.chunk, gdim);
 }
 
@@ -1346,9 +1402,17 @@ static_assert(sizeof(CoopWave) * (O3D_BLOCK / O3D_WAVE) >= kCertLdsBytes, "the c
 // the previous registration's row from memory: wrong by one registration's sums from the third registration on a context on).
 template <int EST, bool TN>
 __device__ __forceinline__ void pass_body(const PassArgs &a, const GridParams &gp, CoopWave *wls) {
-  cert_body<EST, true>(a, reinterpret_cast<unsigned char *>(wls));
+  PASS_MARK(0)
+#if O3D_PASS_PROF
+  if ((threadIdx.x & 63) == 0)  // where the wavefront runs: HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID
+    g_pass_t[blockIdx.x * 4 + (threadIdx.x >> 6)][6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                       ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+  cert_body<EST, true, TN>(a, reinterpret_cast<unsigned char *>(wls));
+  PASS_MARK(4)
   __syncthreads();  // (every return of cert_body is taken by the whole workgroup)
   search_coop_body<EST, TN>(a, gp, wls);
+  PASS_MARK(5)
 }
 template <int EST, bool TN>
 __global__ __launch_bounds__(O3D_BLOCK, 4) void k_icp_pass(PassArgs a, GridParams gp) {
@@ -2444,6 +2508,38 @@ int o3d_launch_pass(o3d_ctx *ctx, double *dev_sums_out, int fuse_solve) {
 #undef O3D_LAUNCH_EST
   O3D_HIP(ctx, hipGetLastError());
   if (ctx->tail_check && pl.tail && !check_done) O3D_TRY(o3d_tail_check_after(ctx, ctx->stream, nparts, dev_sums_out, "pass"));
+#if O3D_PASS_PROF
+  if (pl.one_launch) {
+    static unsigned long long ht[4 * O3D_MAX_GRID][O3D_PASS_MARKS];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_pass_t), sizeof(ht));
+    const int nw = 4 * pl.grows;
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < nw; w++) if (ht[w][0] && ht[w][0] < t0) t0 = ht[w][0];
+    // per milestone: mean and latest time after the first wavefront came in; then per XCD the latest "loop done" and "all done"
+    double mean[6] = {0}, last[6] = {0}, xl[8] = {0}, xe[8] = {0}, xm[8] = {0};
+    for (int w = 0; w < nw; w++) {
+      const int xcd = (w / 4) & 7;
+      for (int i = 0; i < 6; i++) {
+        const double t = ht[w][i] >= t0 ? (ht[w][i] - t0) / 100.0 : 0.0;
+        mean[i] += t / nw;
+        if (t > last[i]) last[i] = t;
+        if (i == 2) { xm[xcd] += t / (nw / 8); if (t > xl[xcd]) xl[xcd] = t; }
+        if (i == 5 && t > xe[xcd]) xe[xcd] = t;
+      }
+    }
+    fprintf(stderr, "pass milestones, us after the first wavefront came in (mean / latest wavefront): in %.1f/%.1f loop starts %.1f/%.1f loop done %.1f/%.1f "
+            "workgroup's loops done %.1f/%.1f certificate half done %.1f/%.1f all done %.1f/%.1f | per XCD loop done mean/latest, all done:",
+            mean[0], last[0], mean[1], last[1], mean[2], last[2], mean[3], last[3], mean[4], last[4], mean[5], last[5]);
+    for (int x = 0; x < 8; x++) fprintf(stderr, " [%.0f/%.0f %.0f]", xm[x], xl[x], xe[x]);
+    fprintf(stderr, "\n");
+    if (const char *dump = getenv("O3D_PASS_PROF_DUMP")) {  // raw marks of this pass, appended
+      if (FILE *f = fopen(dump, "ab")) { fwrite(ht, sizeof(ht[0]), nw, f); fclose(f); }
+    }
+    memset(ht, 0, sizeof(ht));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pass_t), ht, sizeof(ht));
+  }
+#endif
 #if O3D_SRCH_PROF
   {
     unsigned long long hp[8];

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the first passes of a registration from scratch (10 M x 10 M, device-generated config-3 scene) for the
 search radii 2 and 4 spacings (point-to-plane) and 3 spacings (point-to-point), with a checksum of the final correspondences
-(library variants must agree).  usage: search_ab.py [tag]"""
+(library variants must agree).  AB_ONLY=p2l_r2[,...] runs the named scenes once.  usage: search_ab.py [tag]"""
 import json, os, sys, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,8 +20,10 @@ out = {"tag": tag}
 for name, rs, est, nrm in (("p2l_r2", 2.0, reg.TransformationEstimationPointToPlane(), sc["normals"]),
                            ("p2l_r4", 4.0, reg.TransformationEstimationPointToPlane(), sc["normals"]),
                            ("p2p_r3", 3.0, reg.TransformationEstimationPointToPoint(), None)):
+    if os.environ.get("AB_ONLY") and name not in os.environ["AB_ONLY"].split(","):
+        continue
     best = None
-    for rep in range(3):
+    for rep in range(1 if os.environ.get("AB_ONLY") else 3):
         sess = reg.IcpSession(ctx).setup(sc["source"], sc["target"], nrm, rs * s, np.eye(4), est, reg.ICPConvergenceCriteria(0, 0, 6))
         sess.profile(True)
         for _ in range(7):
