@@ -33,11 +33,18 @@
 #endif
 #if O3D_PASS_PROF  // profile build only (scripts/pass_phases.sh): when every wavefront of k_icp_pass passes its milestones (100 MHz
                    // clock; plain stores to the wavefront's own slots -- atomics on shared counters cost more than the pass)
-#define O3D_PASS_MARKS 8
+#define O3D_PASS_MARKS 16
 __device__ unsigned long long g_pass_t[4 * O3D_MAX_GRID][O3D_PASS_MARKS];
 #define PASS_MARK(i) { if ((threadIdx.x & 63) == 0) g_pass_t[blockIdx.x * 4 + (threadIdx.x >> 6)][i] = wall_clock64(); }
+// shader-clock cycles per phase of the certificate loop, summed over the wavefront's trips (slots 8..)
+#define LOOP_T_DECL long long t_loop_prev = clock64(); long long t_loop_sum[6] = {0, 0, 0, 0, 0, 0};
+#define LOOP_T(i) { const long long t_now = clock64(); t_loop_sum[i] += t_now - t_loop_prev; t_loop_prev = t_now; }
+#define LOOP_T_STORE { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 6; i_++) g_pass_t[blockIdx.x * 4 + (threadIdx.x >> 6)][8 + i_] = (unsigned long long)t_loop_sum[i_]; }
 #else
 #define PASS_MARK(i)
+#define LOOP_T_DECL
+#define LOOP_T(i)
+#define LOOP_T_STORE
 #endif
 #if O3D_SRCH_PROF  // profile build only (scripts/search_phases.sh): wave cycles per phase of a search trip
 __device__ unsigned long long g_srch_prof[8];
@@ -922,10 +929,10 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
   double T[12], w[4];
   load_update(a.st, T, w);
   const float thrf = (float)a.thr;
-  constexpr bool stream = STREAM;  // (a run-time flag was merged into one path by the compiler, which dropped the hint)
   Sums S = {0.0, 0.0, 0.0, 0u};
   unsigned long long ncert = 0;
   uint32_t nwork = 0;  // wave-uniform
+  constexpr bool stream = STREAM;  // (a run-time flag was merged into one path by the compiler, which dropped the hint)
   // The loop is software-pipelined over three trips: while trip t is worked through, the matched records of trip t + 1 are
   // being gathered (their positions arrived a trip ago) and the points, positions and bounds of trip t + 2 are being read.
   // A wavefront otherwise waits out two dependent trips to memory per trip (point -> record) with only the other three
@@ -993,9 +1000,11 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     r0 = load_b(a0, wr.first);
   }
   PASS_MARK(1)
+  LOOP_T_DECL
   for (int64_t base = wr.first; base < wr.end; base += wr.stride) {
     r1 = load_b(a1, base + wr.stride);
     a2 = load_a(base + 2 * wr.stride);
+    LOOP_T(0)  // waited for the positions read a trip ago; gathers and stream loads issued
     const int64_t i = base + lane;
     const bool valid = i < wr.end;
     double x = a0.x, y = a0.y, z = a0.z;
@@ -1034,6 +1043,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
         moved = sqrtf((float)(mx * mx + my * my + mz * mz)) * (1.0f + 1e-6f);  // NaN for a non-finite point: never certified
       }
     }
+    LOOP_T(1)  // update applied (waited for the point read two trips ago), point written back
     // what the stored bound is still worth at the new position (<= 0, or NaN: nothing)
     const float lbc = stays ? lbv : lbv * (1.0f - 1e-6f) - moved;
     double d2 = 0.0;
@@ -1043,6 +1053,7 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
       d2 = d2 + ddy * ddy;
       d2 = d2 + ddz * ddz;
     }
+    LOOP_T(2)  // waited for the record gathered a trip ago; distance
     bool certified = false;
     if (valid && lbc > 0.f) {
       const float lb2 = lbc * lbc * (1.0f - 1e-6f);
@@ -1063,8 +1074,11 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
     if (valid && !certified) a.work[wr.list + nwork + __popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)i;
     nwork += (uint32_t)__popcll(need);
     if (a.stats) ncert += __popcll(__ballot(certified));
+    LOOP_T(3)  // certificate test, bound and work list written
     push_sums<EST>(vb, lane, S, use, x, y, z, p, n0, n1, n2, d2, cx0, cy0, cz0, tc, is, a.slg, a.slp);
+    LOOP_T(4)  // sums
   }
+  LOOP_T_STORE
   PASS_MARK(2)
   if (lane == 0) {
     a.work_count[wr.seg] = nwork;

@@ -5,7 +5,9 @@ by the order in which their workgroup was dispatched on its XCD.  usage: pass_ma
 import sys
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4096, 8)
+a = np.fromfile(sys.argv[1], dtype=np.uint64)
+marks = 16 if a.size % (4096 * 16) == 0 else 8
+a = a.reshape(-1, 4096, marks)
 for ps in range(a.shape[0]):
     m = a[ps]
     t0 = m[:, 0].min()
@@ -29,3 +31,10 @@ for ps in range(a.shape[0]):
              [round(float(loop[xcc == k].mean()), 1) for k in np.unique(xcc)]))
     print("   loop done by dispatch order of the workgroup on its XCD (quarters: the 1st, 2nd, 3rd, 4th workgroup of a CU): %s"
           % [round(float(loop[(wg // 32) == k].mean()), 1) for k in range(4)])
+    if marks == 16:
+        ph = m[:, 8:13].astype(np.float64)
+        tot = ph.sum(1)
+        names = ["top: wait for positions, issue loads", "update + write-back (waits for the point)", "wait for the record, distance", "certificate test, bound, work list", "sums"]
+        print("   shader-clock cycles per wavefront and trip (mean over wavefronts; 38.15 trips): total %.0f" % (tot.mean() / 38.15))
+        for i, nm in enumerate(names):
+            print("      %-46s %7.0f  (%4.1f %%)" % (nm, ph[:, i].mean() / 38.15, 100 * ph[:, i].mean() / tot.mean()))
