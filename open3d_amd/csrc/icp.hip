@@ -1060,6 +1060,11 @@ __device__ __forceinline__ void cert_body(const PassArgs &a, unsigned char *lds_
       certified = has_prev ? (float)d2 * (1.0f + 1e-6f) < lb2   // m is strictly nearer than everything else
                            : lb2 > thrf * (1.0f + 1e-6f);        // nothing within the radius
     }
+    // A point the pending update leaves where it is, bit for bit, needs no bound at all: its entry is the exact result of the
+    // pass before at this very position (every pass leaves exact results behind: searched or certified), so it stands.  Near
+    // convergence this takes most of the points no bound can certify -- ties and near-ties, which a search resolves in fp64
+    // one at a time -- off the work list: they rest like everybody else.
+    if (valid && apply && stays) certified = true;
     // A certified query keeps its correspondence entry as it is -- the entry already names m (or nothing, without a match):
     // the search that found m wrote it, and no later pass touched it -- so the entry is not rewritten here (4 of the 124
     // bytes a certified point costs).  The one case that would change it, m still the nearest point but now beyond the
@@ -1945,6 +1950,7 @@ __device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsign
   }
   if (tid < O3D_NSUMS) store_device_coherent(a.gsums + g * O3D_NSUMS + k, acc);
   if (!last_to_arrive(a.tickets + 32, ngroups)) return;
+  PASS_MARK(14)  // (only the workgroup that ends the pass gets here)
   __shared__ double q[O3D_NSUMS];
   if (tid < O3D_NSUMS) {
     double v[32];
@@ -1970,10 +1976,12 @@ __device__ __forceinline__ void pass_tail(const PassArgs &a, double *lds, unsign
   __shared__ IcpState ls;
   state_copy(reinterpret_cast<uint32_t *>(&ls), reinterpret_cast<const uint32_t *>(a.st_rw));
   __syncthreads();
+  PASS_MARK(15)
   if (tid >= O3D_WAVE && tid < 2 * O3D_WAVE) write_log_row(&ls, q, a.log, a.log_rows, tid - O3D_WAVE);
   __syncthreads();
   if (tid == 0) solve_body(&ls, q, a.has_normals, a.log, a.log_rows);
   __syncthreads();
+  PASS_MARK(7)
   state_copy(reinterpret_cast<uint32_t *>(a.st_rw), reinterpret_cast<const uint32_t *>(&ls));
 }
 

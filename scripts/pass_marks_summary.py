@@ -38,3 +38,9 @@ for ps in range(a.shape[0]):
         print("   shader-clock cycles per wavefront and trip (mean over wavefronts; 38.15 trips): total %.0f" % (tot.mean() / 38.15))
         for i, nm in enumerate(names):
             print("      %-46s %7.0f  (%4.1f %%)" % (nm, ph[:, i].mean() / 38.15, 100 * ph[:, i].mean() / tot.mean()))
+        last = np.nonzero(m[:, 7])[0]
+        if len(last):
+            w = last[0]
+            t5 = lambda i: (int(m[w, i]) - int(t0)) / 100.0
+            print("   the workgroup that ends the pass (us after the first wavefront came in): own search done and group rows added %.1f, all rows added and state read %.1f, "
+                  "estimate solved %.1f, out %.1f" % (t5(14), t5(15), t5(7), t5(5)))

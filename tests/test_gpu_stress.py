@@ -225,7 +225,7 @@ def test_seeded_search_walk_on_lattice_with_ties(ctx, oracle):
             shift(1e-9, 0, 0), shift(0, 2e-5, -1e-5), shift(1e-3, -1e-3, 0), shift(0.03, 0, 0.01), shift(0.1, 0.05, 0),
             shift(0.119, -0.049, -0.01), shift(-0.25, 0, 0), shift(0, 0, 0), shift(0, 0, 30.0), shift(1e-6, 0, 0), shift(0, 0, -30.0)]
     for use_tile in (True, False):
-        ctx.debug_set(use_tile_search=use_tile)
+        ctx.debug_set(use_tile_search=use_tile, collect_tile_stats=use_tile)
         sess = reg.IcpSession(ctx).setup(src, tgt, None, r, np.eye(4), reg.TransformationEstimationPointToPoint(),
                                          reg.ICPConvergenceCriteria(0, 0, 100))
         cur = src.copy()
@@ -233,12 +233,18 @@ def test_seeded_search_walk_on_lattice_with_ties(ctx, oracle):
             if k > 0:
                 sess.set_update(U)
                 cur = oracle.transform_points(U, cur)
+            if use_tile:
+                ctx.tile_stats(reset=True)
             sess.enqueue_pass()
             got = sess.fetch()
             corr, nc, sd2, fit, rmse = oracle.correspondences(cur, tgt, r)
             assert np.array_equal(got.corr_, corr), "pass %d (tile search %s)" % (k, use_tile)
             assert got.fitness_ == fit and rel_err(got.inlier_rmse_, rmse) < 1e-12 if nc else got.fitness_ == 0.0
-    ctx.debug_set(use_tile_search=True)
+            if use_tile and k > 0 and not U[:3, 3].any():
+                # an update that moves nothing: every entry stands as the pass before left it -- ties included, which no
+                # bound can certify -- and nothing is searched
+                assert ctx.tile_stats(reset=True)["certified"] == len(src), k
+    ctx.debug_set(use_tile_search=True, collect_tile_stats=False)
 
 
 def test_staged_copies_back_to_back(ctx):
