@@ -33,7 +33,7 @@
 #endif
 #if O3D_PASS_PROF  // profile build only (scripts/pass_phases.sh): when every wavefront of k_icp_pass passes its milestones (100 MHz
                    // clock; plain stores to the wavefront's own slots -- atomics on shared counters cost more than the pass)
-#define O3D_PASS_MARKS 16
+#define O3D_PASS_MARKS 24
 __device__ unsigned long long g_pass_t[4 * O3D_MAX_GRID][O3D_PASS_MARKS];
 #define PASS_MARK(i) { if ((threadIdx.x & 63) == 0) g_pass_t[blockIdx.x * 4 + (threadIdx.x >> 6)][i] = wall_clock64(); }
 // shader-clock cycles per phase of the certificate loop, summed over the wavefront's trips (slots 8..)
@@ -1826,6 +1826,7 @@ __device__ __forceinline__ void solve_body(IcpState *__restrict__ st, const doub
   }
   if (pass >= st->max_iter) { st->done = 1; return; }
 
+  PASS_MARK(16)
   double upd[16];
   mat4_identity(upd);
   if (nc > 0.0) {
@@ -1837,16 +1838,20 @@ __device__ __forceinline__ void solve_body(IcpState *__restrict__ st, const doub
           for (int c = a; c < 6; c++) { A[a * 6 + c] = q[k]; A[c * 6 + a] = q[k]; k++; }
         for (int a = 0; a < 6; a++) b[a] = -q[21 + a];
         ldlt_solve6(A, b, x);
+        PASS_MARK(17)
         vec6_to_mat4(x, upd);
       }
     } else {
       umeyama_from_sums(q, st->centre, st->with_scaling, upd);
     }
   }
+  PASS_MARK(18)
   for (int i = 0; i < 16; i++) st->update[i] = upd[i];
   mat4_mul(upd, st->T, st->T);
   st->apply_update = 1;
+  PASS_MARK(19)
   update_skips_certificates(st, upd);
+  PASS_MARK(20)
 }
 
 // The loop state is staged in LDS for the one lane that runs the estimate (dozens of dependent global accesses otherwise)

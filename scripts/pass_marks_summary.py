@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.uint64)
-marks = 16 if a.size % (4096 * 16) == 0 else 8
+marks = 24 if a.size % (4096 * 24) == 0 else (16 if a.size % (4096 * 16) == 0 else 8)
 a = a.reshape(-1, 4096, marks)
 for ps in range(a.shape[0]):
     m = a[ps]
@@ -31,7 +31,7 @@ for ps in range(a.shape[0]):
              [round(float(loop[xcc == k].mean()), 1) for k in np.unique(xcc)]))
     print("   loop done by dispatch order of the workgroup on its XCD (quarters: the 1st, 2nd, 3rd, 4th workgroup of a CU): %s"
           % [round(float(loop[(wg // 32) == k].mean()), 1) for k in range(4)])
-    if marks == 16:
+    if marks >= 16:
         ph = m[:, 8:13].astype(np.float64)
         tot = ph.sum(1)
         names = ["top: wait for positions, issue loads", "update + write-back (waits for the point)", "wait for the record, distance", "certificate test, bound, work list", "sums"]
@@ -44,3 +44,6 @@ for ps in range(a.shape[0]):
             t5 = lambda i: (int(m[w, i]) - int(t0)) / 100.0
             print("   the workgroup that ends the pass (us after the first wavefront came in): own search done and group rows added %.1f, all rows added and state read %.1f, "
                   "estimate solved %.1f, out %.1f" % (t5(14), t5(15), t5(7), t5(5)))
+            if marks >= 24 and m[w, 20]:
+                print("      the estimate on its one lane: criteria %.1f, 6 x 6 LDLT %.1f, angles to matrix %.1f, composition %.1f, certificate forecast %.1f us"
+                      % (t5(16) - t5(15), t5(17) - t5(16), t5(18) - t5(17), t5(19) - t5(18), t5(20) - t5(19)))
