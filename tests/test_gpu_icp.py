@@ -85,6 +85,32 @@ def test_icp_per_pass_log_matches_oracle(ctx, oracle):
     assert np.array_equal(res.corr_, ref.corr)
 
 
+def test_debug_getters_of_the_processing_order(ctx, oracle):
+    """o3d_debug_get_source_perm / o3d_debug_get_match_positions (tuning hooks): the processing order is a permutation of the
+    source, and the match positions it carries name the cell-sorted target consistently with the correspondences -- none
+    where there is no correspondence, one position per target index."""
+    geometry, reg = _reg()
+    sc = make_scene(30000, 25000, cfg_id=8)
+    s = sc["spacing"]
+    src = sc["source"].copy()
+    src[:500, 2] += 50.0 * s                       # some points without a correspondence
+    sess = reg.IcpSession(ctx).setup(src, sc["target"], None, 2 * s, np.eye(4), reg.TransformationEstimationPointToPoint(),
+                                     reg.ICPConvergenceCriteria(0, 0, 4))
+    sess.run()
+    res = sess.finish()
+    n = len(src)
+    perm, pos = ctx.source_perm(n), ctx.match_positions(n)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    corr = res.corr_[perm]                          # correspondences in processing order
+    none = pos == 0xFFFFFFFF
+    assert np.array_equal(none, corr < 0) and none.sum() >= 500
+    assert pos[~none].max() < len(sc["target"])
+    by_pos = {}
+    for c, q in zip(corr[~none].tolist(), pos[~none].tolist()):
+        assert by_pos.setdefault(q, c) == c         # one target index per position ...
+    assert len(set(by_pos.values())) == len(by_pos)  # ... and one position per target index
+
+
 def test_icp_with_init_and_scaling(ctx, oracle):
     geometry, reg = _reg()
     sc = make_scene(8000, 9000, cfg_id=3, theta_deg=2.0, tau=(4, -3, 2))
